@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — generates tests/golden/*.npz by running the REFERENCE itself.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to the GPU
+box). It imports the reference's llama.model / engine in-process with the three shims of
+SURVEY.md §8c (no file of the reference is edited or copied):
+  1. Tensor.cuda -> identity, torch.cuda.synchronize -> no-op   (llama/model.py:82-83,255-264,302; engine.py:43)
+  2. llama.model.Tokenizer -> stub with the hard-coded ids      (llama/tokenizer.py:14-33; no tokenizer.model offline)
+  3. fp32-shim: Tensor.half / Module.half -> float32            (llama/model.py:115,119,210-224,324,339)
+builds the reference Transformer, overwrites every tensor with the closed-form generator of
+flipped-vqa_amd/fvqa/synth.py, runs forward + backward on the closed-form batch and stores
+what the parity tests compare against: the three losses, LM-head argmax ids, sampled logits
+with top-2 margins, per-layer activation checksums and the trainable gradients.
+
+usage: python oracle/gen_golden.py [case ...]      (default: every case in CASES)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flipped-vqa_amd"))
+from fvqa import synth  # noqa: E402
+
+REF = "/root/reference"
+
+CASES = {
+    # name: (preset, overrides)
+    "tiny_vqa": ("tiny", dict(vaq=False, qav=False)),
+    "tiny_all": ("tiny", dict(vaq=True, qav=True)),
+    "tiny_cold": ("tiny", dict(vaq=True, qav=True, warm=False)),
+    "small_all": ("small", dict(vaq=True, qav=True)),
+    "7b_l2_all": ("7b_l2", dict(vaq=True, qav=True)),
+    "7b_l2_vqa": ("7b_l2", dict(vaq=False, qav=False)),
+}
+
+
+def install_shims():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.Tensor.half = lambda self, *a, **k: self.to(torch.float32)
+    torch.nn.Module.half = lambda self: self.to(torch.float32)
+    sys.path.insert(0, REF)
+    import llama.model as M
+
+    class StubTok:
+        def __init__(self, model_path=None, args=None):
+            self.n_words, self.bos_id, self.eos_id, self.pad_id = 32000, 1, 2, -1
+            self.v_token_id, self.q_token_id, self.a_token_id, self.nl_id = 15167, 16492, 22550, 13
+
+        def decode(self, t):
+            return ""
+
+    M.Tokenizer = StubTok
+    return M
+
+
+def build_reference(M, cfg):
+    args = types.SimpleNamespace(
+        max_feats=cfg.max_feats, bias=cfg.bias, tau=cfg.tau, llama_model_path="/nonexistent/",
+        audio=False, audio_only=False, audio_merge="none", vaq=cfg.vaq, qav=cfg.qav, debug=False,
+        adapter_len=cfg.adapter_len, adapter_layer=cfg.adapter_layer, max_seq_len=cfg.max_seq_len)
+    ma = M.ModelArgs(max_seq_len=cfg.max_seq_len, max_batch_size=2, adapter_len=cfg.adapter_len,
+                     adapter_layer=cfg.adapter_layer, **cfg.params_json())
+    ma.vocab_size = cfg.vocab_size
+    torch.manual_seed(0)
+    # skip the (slow, discarded) default initialisers: every tensor is overwritten below
+    saved = {}
+    for fn in ("kaiming_uniform_", "normal_", "uniform_"):
+        saved[fn] = getattr(torch.nn.init, fn)
+        setattr(torch.nn.init, fn, lambda t, *a, **k: t)
+    try:
+        model = M.Transformer(ma, args)
+    finally:
+        for fn, f in saved.items():
+            setattr(torch.nn.init, fn, f)
+    sd = synth.state_dict(cfg)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.data = sd[n].clone()
+    for n, p in model.named_parameters():          # llama_vqa.py:71-76
+        p.requires_grad = synth.is_trainable(n)
+    return model, args
+
+
+def run_case(M, name):
+    pname, over = CASES[name]
+    cfg = synth.preset(pname, **over)
+    model, args = build_reference(M, cfg)
+    model.train(True)
+    batch = synth.make_batch(cfg, seed=0)
+
+    logits, norms, layer_out = [], [], []
+    model.output.register_forward_hook(lambda m, i, o: logits.append(o.detach()))
+    model.norm.register_forward_hook(lambda m, i, o: norms.append(o.detach()))
+    for lyr in model.layers:
+        lyr.register_forward_hook(lambda m, i, o: layer_out.append(o.detach()))
+
+    vqa, vaq, qav = model(batch)
+    loss = vqa + vaq + qav
+    loss.sum().backward()
+
+    out = {
+        "loss_vqa": np.float32(vqa.item()), "loss_vaq": np.float32(vaq.item()),
+        "loss_qav": np.float32(qav.item()),
+    }
+    rng = np.random.RandomState(7)
+    for si, tag in enumerate(["vqa", "vaq"][: len(logits)]):
+        lg = logits[si].float()                       # (N, S, V)
+        N, S, V = lg.shape
+        flat = lg[:, :-1].reshape(-1, V)
+        top2 = flat.topk(2, dim=-1)
+        out[f"argmax_{tag}"] = top2.indices[:, 0].numpy().astype(np.int32)
+        out[f"margin_{tag}"] = (top2.values[:, 0] - top2.values[:, 1]).numpy().astype(np.float32)
+        rows = rng.randint(0, flat.shape[0], size=256)
+        cols = rng.randint(0, V, size=256)
+        out[f"sample_rows_{tag}"] = rows.astype(np.int32)
+        out[f"sample_cols_{tag}"] = cols.astype(np.int32)
+        out[f"sample_logits_{tag}"] = flat[rows, cols].numpy().astype(np.float32)
+        out[f"logits_absmax_{tag}"] = np.float32(flat.abs().max().item())
+    # per-layer activation checksums; hook order: layer-major, stream-minor (model.py:338-345)
+    n_streams = 1 + int(cfg.vaq) + int(cfg.qav)
+    cs = np.zeros((len(layer_out), 2 + 16), dtype=np.float32)
+    for i, t in enumerate(layer_out):
+        f = t.float().flatten()
+        pick = torch.from_numpy(rng.randint(0, f.numel(), size=16).astype(np.int64))
+        cs[i, 0] = f.mean().item()
+        cs[i, 1] = f.norm().item()
+        cs[i, 2:] = f[pick].numpy()
+        out.setdefault("layer_pick", [])
+        out["layer_pick"].append(pick.numpy())
+    out["layer_pick"] = np.stack(out["layer_pick"]).astype(np.int64)
+    out["layer_checksum"] = cs
+    out["n_streams"] = np.int32(n_streams)
+    # gradients of the trainables
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        g = p.grad
+        key = n.replace(".", "__")
+        if g is None:
+            out[f"gradnone__{key}"] = np.int32(1)
+            continue
+        g = g.float()
+        out[f"gradnorm__{key}"] = np.float32(g.norm().item())
+        if g.numel() <= 65536:
+            out[f"grad__{key}"] = g.numpy().astype(np.float32)
+        else:
+            f = g.flatten()
+            pick = torch.from_numpy(rng.randint(0, f.numel(), size=4096).astype(np.int64))
+            out[f"gradpick__{key}"] = pick.numpy()
+            out[f"gradsample__{key}"] = f[pick].numpy().astype(np.float32)
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[{name}] losses {vqa.item():.6f} {vaq.item():.6f} {qav.item():.6f} -> {path} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
+
+
+def main():
+    names = sys.argv[1:] or list(CASES)
+    M = install_shims()
+    for n in names:
+        run_case(M, n)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""Shared comparison helpers: a step result (losses, grads, logits, layer outputs) against a
+golden fixture produced from the reference by oracle/gen_golden.py."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> (preset, overrides); must mirror oracle/gen_golden.py CASES
+CASES = {
+    "tiny_vqa": ("tiny", dict(vaq=False, qav=False)),
+    "tiny_all": ("tiny", dict(vaq=True, qav=True)),
+    "tiny_cold": ("tiny", dict(vaq=True, qav=True, warm=False)),
+    "small_all": ("small", dict(vaq=True, qav=True)),
+    "7b_l2_all": ("7b_l2", dict(vaq=True, qav=True)),
+    "7b_l2_vqa": ("7b_l2", dict(vaq=False, qav=False)),
+}
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, margin_factor=4.0,
+                        check_argmax=True):
+    """losses: dict task->float; grads: dict name->tensor (CPU); logits: dict task->(N,S,V) tensor;
+    layer_out: list in the reference's hook order (layer-major, stream-minor) of (N,S,D) tensors.
+    Returns a dict of measured errors; raises AssertionError on the first violation."""
+    rep = {}
+    for t in ("vqa", "vaq", "qav"):
+        ref = float(g[f"loss_{t}"])
+        got = float(losses[t])
+        err = abs(got - ref) / max(abs(ref), 1e-12) if ref != 0 else abs(got)
+        rep[f"loss_{t}"] = err
+        assert err <= rtol, f"loss_{t}: got {got} ref {ref} rel {err:.3e} > {rtol}"
+    if logits is not None:
+        for t in ("vqa", "vaq"):
+            if f"argmax_{t}" not in g or t not in logits:
+                continue
+            lg = logits[t].detach().double().cpu()
+            V = lg.shape[-1]
+            flat = lg[:, :-1].reshape(-1, V)
+            rows, cols = g[f"sample_rows_{t}"].astype(np.int64), g[f"sample_cols_{t}"].astype(np.int64)
+            got = flat[torch.from_numpy(rows), torch.from_numpy(cols)].numpy()
+            amax = float(g[f"logits_absmax_{t}"])
+            err = float(np.abs(got - g[f"sample_logits_{t}"]).max() / amax)
+            rep[f"logits_{t}"] = err
+            assert err <= rtol, f"logits_{t}: max abs err / absmax = {err:.3e} > {rtol}"
+            if check_argmax:
+                am = flat.argmax(-1).numpy()
+                # rows whose reference top-2 margin is inside the error band are ties, not mismatches
+                decided = g[f"margin_{t}"] > margin_factor * rtol * amax
+                bad = (am != g[f"argmax_{t}"]) & decided
+                rep[f"argmax_{t}_decided"] = int(decided.sum())
+                assert not bad.any(), f"argmax_{t}: {int(bad.sum())} of {int(decided.sum())} decided rows differ"
+    if layer_out is not None:
+        cs, pick = g["layer_checksum"], g["layer_pick"]
+        assert len(layer_out) == cs.shape[0], (len(layer_out), cs.shape)
+        worst = 0.0
+        for i, t in enumerate(layer_out):
+            f = t.detach().double().cpu().flatten()
+            nrm = float(cs[i, 1])
+            e_norm = abs(float(f.norm()) - nrm) / nrm
+            scale = nrm / np.sqrt(f.numel())
+            e_pick = float(np.abs(f[torch.from_numpy(pick[i])].numpy() - cs[i, 2:]).max() / scale)
+            worst = max(worst, e_norm, e_pick)
+            assert e_norm <= rtol and e_pick <= 4 * rtol, f"layer_out[{i}]: norm {e_norm:.3e} pick {e_pick:.3e}"
+        rep["layer_out"] = worst
+    for k in g:
+        if not k.startswith("gradnorm__"):
+            continue
+        name = k[len("gradnorm__"):].replace("__", ".")
+        gr = grads[name].detach().double().cpu()
+        nref = float(g[k])
+        if nref == 0.0:
+            assert float(gr.norm()) <= 1e-12, name
+            continue
+        e = abs(float(gr.norm()) - nref) / nref
+        key = k[len("gradnorm__"):]
+        if f"grad__{key}" in g:
+            e = max(e, float(np.abs(gr.numpy() - g[f"grad__{key}"]).max() / np.abs(g[f"grad__{key}"]).max()))
+        else:
+            pk = torch.from_numpy(g[f"gradpick__{key}"])
+            ref = g[f"gradsample__{key}"]
+            e = max(e, float(np.abs(gr.flatten()[pk].numpy() - ref).max() / np.abs(ref).max()))
+        rep[f"grad:{name}"] = e
+        assert e <= rtol, f"grad {name}: rel err {e:.3e} > {rtol}"
+    return rep

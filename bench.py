@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Flipped-VQA training samples/s on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+One step = one full training step of the hot path on one synthetic batch already resident in
+HBM: LLaMA-Adapter forward over the frame-spliced token stream, the flipped loss(es), backward,
+loss-scaler unscale + grad norm, [RCCL all-reduce of the flat trainable gradient], AdamW.
+Workload at N=1 = BASELINE configs[1]: LLaMA-7B (random-init, closed-form), bf16, seq_len 128,
+batch 8 per GPU, max_feats 10, VQA loss only. N>1 = the same per-GPU work on every rank (weak
+scaling), one all-reduce(mean) of 4.5 M fp32 gradients per step.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     — the dominant kernel (bf16 projection GEMM gemm_nt_128): algorithmic FLOPs per
+                 launch / average launch time from HIP events around each launch in a separate
+                 instrumented pass of the same steps, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  step_roofline— algorithmic FLOPs of the whole step (SURVEY §8d formula) / step time;
+  cpu_baseline — the CPU oracle (oracle/ref_cpu.py) timed on this host's cores on a bounded
+                 sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "flipped-vqa_amd"))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("FVQA_SYNTHETIC_TOKENIZER", "1")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK = 2.5e15      # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def step_flops(D, H, L, Hf, V, N, S, A, F, tasks):
+    """Algorithmic FLOPs of one training step per GPU: frozen weights => dX only."""
+    T = N * S
+    tot = 0.0
+    for t in tasks:
+        lin = 2 * T * (4 * D * D + 3 * D * Hf)
+        fwd = L * (lin + 4 * N * S * (A + S) * D + 4 * A * D * D)
+        bwd = L * (lin + 10 * N * S * (A + S) * D + 4 * A * D * D)
+        head = 2 * T * D * V if t != "qav" else 2 * N * (S - 1) * D * F
+        tot += fwd + bwd + head * (2 if t != "qav" else 3)
+    tot += 2 * 2 * N * F * 768 * D
+    return tot
+
+
+def cpu_baseline_leg(seq_len, max_feats):
+    """Oracle fwd+bwd at 7B width on the host cores, bounded: 1 and 2 layers, B=2, VQA only;
+    the per-layer and the fixed cost are separated and scaled to 32 layers."""
+    from fvqa import synth
+    from oracle import ref_cpu
+    times = {}
+    for L in (1, 2):
+        cfg = synth.preset("7b_l2", n_layers=L, adapter_layer=L, max_seq_len=seq_len, max_feats=max_feats,
+                           batch_size=2)
+        model = ref_cpu.RefModel(cfg, synth.state_dict(cfg), dtype=torch.float32)
+        batch = synth.make_batch(cfg, seed=0)
+        model.step(batch)                      # warm-up
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            model.step(batch)
+        times[L] = (time.perf_counter() - t0) / reps
+        del model
+    per_layer = max(times[2] - times[1], 1e-9)
+    fixed = max(times[1] - per_layer, 0.0)
+    full = fixed + 32 * per_layer              # one 7B step on B=2 samples
+    return {"value": 2.0 / full, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ref_cpu.py fp32, 7B width, B=2 S={seq_len} VQA-only, timed at 1 and 2 layers "
+                      f"({times[1]:.2f}s, {times[2]:.2f}s) and scaled to 32 layers + head ({full:.1f}s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="7B")
+    ap.add_argument("--batch_size", type=int, default=8)
+    ap.add_argument("--seq_len", type=int, default=128)
+    ap.add_argument("--vaq", action="store_true")
+    ap.add_argument("--qav", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--n_layers", type=int, default=0, help="debug only: reduced depth (marks the line invalid)")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+
+    import util.misc as misc
+    from fvqa import ops, synth
+    from fvqa.optim import FusedAdamW, param_groups_weight_decay
+    from fvqa.parallel import DataParallel
+    from llama_vqa import LLaMA_VQA
+
+    args = types.SimpleNamespace(
+        llama_model_path="/nonexistent/", model=a.model, max_seq_len=a.seq_len, adapter_len=10,
+        adapter_layer=40 if a.model == "13B" else 32, max_feats=10, bias=3.5, tau=100.0, vaq=a.vaq, qav=a.qav,
+        audio=False, audio_only=False, audio_merge="none", debug=False, synthetic=True, random_init=True,
+        dtype=a.dtype, accum_iter=1, weight_decay=0.14)
+    kw = {}
+    if a.n_layers:
+        kw["n_layers"] = a.n_layers
+        args.adapter_layer = a.n_layers
+    t_build = time.time()
+    model = LLaMA_VQA(args, **kw)
+    model.to(dev)
+    p = model.params
+    eff = a.batch_size * world
+    lr = 9e-2 * eff / 256
+    opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=lr, betas=(0.9, 0.95),
+                     flat=model.flat_params())
+    net = model
+    if world > 1:
+        net = DataParallel(model)
+        opt.grad_sync = net.sync_grads
+    scaler = misc.NativeScalerWithGradNormCount()
+
+    cfg = synth.SynthConfig(dim=p.dim, n_heads=p.n_heads, n_layers=p.n_layers, vocab_size=model.vocab_size,
+                            max_seq_len=a.seq_len, batch_size=a.batch_size, vaq=a.vaq, qav=a.qav)
+    n_batches = 4
+    batches = []
+    for i in range(n_batches):
+        b = synth.make_batch(cfg, seed=1234 + rank + world * i)
+        b["video"] = b["video"].to(dev)
+        for k in ("text_id", "label", "video_index"):
+            b[k] = {t: v.to(dev) for t, v in b[k].items()}
+        batches.append(b)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"[bench] model built in {time.time() - t_build:.1f}s; "
+              f"{torch.cuda.memory_allocated() / 2**30:.1f} GiB allocated", file=sys.stderr, flush=True)
+
+    def one_step(i):
+        opt.zero_grad()
+        vqa, vaq, qav = net(batches[i % n_batches])
+        loss = vqa + vaq + qav
+        scaler(loss, opt, parameters=None, update_grad=True)
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = one_step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.sum())
+    ms = dt / a.steps * 1e3
+    value = a.batch_size * world * a.steps / dt
+
+    # ---- instrumented pass: HIP events around every launch of the dominant kernel
+    roof = None
+    if rank == 0:
+        rec = []
+        ops.GEMM_TIMING = rec
+        for i in range(a.steps):
+            one_step(i)
+        torch.cuda.synchronize()
+        ops.GEMM_TIMING = None
+        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, key) in rec if key == "bf16_bf16_none"] \
+            if a.dtype == "bf16" else [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, key) in rec]
+        if sel:
+            tot_t = sum(s[0] for s in sel)
+            tot_f = sum(s[1] for s in sel)
+            n = len(sel)
+            peak = MFMA_BF16_PEAK if a.dtype == "bf16" else 157.3e12
+            roof = {"bound": "mfma", "kernel": "gemm_nt_128<bf16,bf16,glds,none>" if a.dtype == "bf16" else "gemm_nt_128<f32>",
+                    "achieved": tot_f / tot_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                    "frac": tot_f / tot_t / peak, "traffic": None, "launches_per_step": n // a.steps,
+                    "avg_launch_us": tot_t / n * 1e6, "avg_flops_per_launch": tot_f / n}
+
+    if rank == 0:
+        tasks = ["vqa"] + (["vaq"] if a.vaq else []) + (["qav"] if a.qav else [])
+        L = len(model.engine_layer_ids())
+        Hf = model.layers[0].feed_forward.w1.weight.shape[0]
+        fl = step_flops(p.dim, p.n_heads, L, Hf, model.vocab_size, a.batch_size, a.seq_len, 10, 10, tasks)
+        peak = MFMA_BF16_PEAK if a.dtype == "bf16" else 157.3e12
+        out = {
+            "metric": "train samples/sec LLaMA-7B seq128 max_feats=10" if a.model == "7B" else f"train samples/sec LLaMA-{a.model}",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic (closed-form random-init weights, synthetic NExT-QA-shaped batches resident in HBM)",
+            "config": {"workload": f"LLaMA-{a.model} {a.dtype} seq_len={a.seq_len} batch={a.batch_size}/GPU max_feats=10 "
+                                   f"losses={'+'.join(tasks)} fwd+bwd+AdamW, {L} layers",
+                       "global_batch": a.batch_size * world, "seq_len": a.seq_len,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "loss": loss_val,
+            "roofline": roof,
+            "step_roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12,
+                              "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / peak, "flops_per_step": fl},
+        }
+        if a.n_layers:
+            out["invalid"] = "reduced depth (debug run)"
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline_leg(a.seq_len, 10)
+            except Exception as e:   # the baseline leg must never take the GPU measurement down
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

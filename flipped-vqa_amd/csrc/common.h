@@ -1,0 +1,100 @@
+// Shared device helpers for the Flipped-VQA gfx950 kernels. CDNA4 only: 64-lane wavefronts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "../../include/fvqa.h"
+
+#define FVQA_WAVE 64
+
+typedef __hip_bfloat16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define FVQA_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return -(int)e__ - 1000;           \
+  } while (0)
+
+// ---- storage <-> fp32 ------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned)b) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-nearest-even, NaN preserved)
+  bf16_t h = __float2bfloat16(f);
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+
+template <typename T> struct Vec4;  // 4 consecutive elements
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    uint2 t;
+    t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+    t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = t;
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return __bfloat162float(x); }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return __float2bfloat16(x); }
+// round-trip through the storage type (the reference rounds at these points)
+template <typename T> __device__ __forceinline__ float round_to(float x) { return to_f32<T>(from_f32<T>(x)); }
+
+// ---- wave / block reductions -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the 4 lanes of an aligned quad (lane ^ 1, lane ^ 2)
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is 4 floats of LDS
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+static inline int fvqa_dtype_ok(int dt) { return dt == FVQA_F32 || dt == FVQA_BF16; }
+static inline size_t fvqa_dtype_size(int dt) { return dt == FVQA_F32 ? 4 : 2; }

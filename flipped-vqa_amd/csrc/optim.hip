@@ -1,0 +1,133 @@
+// Loss-scaler bookkeeping, gradient norm and AdamW for the ~4.5 M trainable fp32 scalars
+// (reference util/misc.py:259-273,282-294 + torch GradScaler/AdamW called from train.py:120-121).
+// Everything the optimizer step needs stays on the device: the scale, the found-inf flag and the
+// step counter are device scalars, so a training step issues no device->host read here.
+#include "common.h"
+
+namespace {
+
+constexpr int NB = 64;   // partial blocks per segment
+
+// grid (NB, n_seg): g *= 1/scale in place; partial sum of squares + non-finite flag per block
+__global__ __launch_bounds__(256) void unscale_sq_k(float* __restrict__ grad, const int64_t* __restrict__ seg_off,
+                                                    const float* __restrict__ scale, float* __restrict__ part) {
+  __shared__ float red[4];
+  const int seg = blockIdx.y;
+  const int64_t lo = seg_off[seg], hi = seg_off[seg + 1];
+  const float inv = 1.f / scale[0];
+  float sq = 0.f, bad = 0.f;
+  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)NB * 256) {
+    const float g = grad[i] * inv;
+    grad[i] = g;
+    sq += g * g;
+    if (!isfinite(g)) bad = 1.f;
+  }
+  sq = block_sum_256(sq, red);
+  bad = block_sum_256(bad, red);
+  if (threadIdx.x == 0) {
+    part[((size_t)seg * NB + blockIdx.x) * 2] = sq;
+    part[((size_t)seg * NB + blockIdx.x) * 2 + 1] = bad;
+  }
+}
+
+// one thread per segment sums its NB partials in fixed order; thread 0 then forms the total norm
+__global__ __launch_bounds__(256) void norm_finish_k(const float* __restrict__ part, int n_seg,
+                                                     float* __restrict__ seg_sq, float* __restrict__ found_inf,
+                                                     float* __restrict__ total_norm) {
+  __shared__ float red[4];
+  float tot = 0.f, bad = 0.f;
+  for (int s = threadIdx.x; s < n_seg; s += 256) {
+    float a = 0.f;
+    for (int b = 0; b < NB; ++b) {
+      a += part[((size_t)s * NB + b) * 2];
+      bad += part[((size_t)s * NB + b) * 2 + 1];
+    }
+    seg_sq[s] = a;
+    tot += a;
+  }
+  tot = block_sum_256(tot, red);
+  bad = block_sum_256(bad, red);
+  if (threadIdx.x == 0) {
+    total_norm[0] = sqrtf(tot);
+    found_inf[0] = (bad > 0.f || !isfinite(tot)) ? 1.f : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const float* __restrict__ g,
+                                               float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                               float b1, float b2, float eps, float wd,
+                                               const float* __restrict__ step, const float* __restrict__ found_inf) {
+  if (found_inf && found_inf[0] != 0.f) return;       // GradScaler.step: skip the whole update
+  const float t = step[0] + 1.f;
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2s = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+    pi -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+// after every group's adamw_k: advance the step counter and the dynamic loss scale
+// (torch.cuda.amp.GradScaler.update: x backoff on overflow, x growth after `interval` clean steps)
+__global__ void scaler_update_k(float* __restrict__ step, float* __restrict__ scale, float* __restrict__ tracker,
+                                const float* __restrict__ found_inf, float growth, float backoff, float interval) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (found_inf[0] != 0.f) {
+    if (scale) { scale[0] *= backoff; tracker[0] = 0.f; }
+  } else {
+    if (step) step[0] += 1.f;
+    if (scale) {
+      const float t = tracker[0] + 1.f;
+      if (t >= interval) { scale[0] *= growth; tracker[0] = 0.f; }
+      else tracker[0] = t;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t fvqa_grad_norm_workspace(int n_seg) { return (size_t)(n_seg > 0 ? n_seg : 0) * NB * 2 * sizeof(float); }
+
+extern "C" int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n_seg, const float* scale,
+                                      float* seg_sq, float* found_inf, float* total_norm, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (!grad || !seg_off || !scale || !seg_sq || !found_inf || !total_norm || !workspace) return FVQA_EINVAL;
+  if (n_seg <= 0 || n_seg > 65535) return FVQA_ESHAPE;
+  if (workspace_bytes < fvqa_grad_norm_workspace(n_seg)) return FVQA_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(unscale_sq_k, dim3(NB, n_seg), dim3(256), 0, st, grad, seg_off, scale, (float*)workspace);
+  hipLaunchKernelGGL(norm_finish_k, dim3(1), dim3(256), 0, st, (const float*)workspace, n_seg, seg_sq, found_inf,
+                     total_norm);
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, const float* step,
+                               const float* found_inf, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step) return FVQA_EINVAL;
+  if (n <= 0) return FVQA_ESHAPE;
+  int64_t g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(adamw_k, dim3((int)g), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, weight_decay, step, found_inf);
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_scaler_update(float* step, float* scale, float* growth_tracker, const float* found_inf,
+                                  float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+  if (!found_inf || (!step && !scale) || (scale && !growth_tracker)) return FVQA_EINVAL;
+  hipLaunchKernelGGL(scaler_update_k, dim3(1), dim3(64), 0, (hipStream_t)stream, step, scale, growth_tracker,
+                     found_inf, growth_factor, backoff_factor, (float)growth_interval);
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_version(void) { return 1; }
+extern "C" const char* fvqa_arch(void) { return "gfx950"; }

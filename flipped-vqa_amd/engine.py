@@ -1,0 +1,54 @@
+"""`engine.train_one_epoch` with the reference's signature and return value (reference
+engine.py:10-56): per-iteration LR schedule, forward, sum of the three flipped losses, finite
+check, gradient accumulation through the loss scaler, meters.
+
+Host-side differences that do not change results: the three loss values come back in ONE
+device->host transfer per iteration instead of four `.item()` calls + a full device sync, and the
+logging period is clamped to >= 1 (the reference crashes on loaders shorter than 4 batches).
+"""
+import math
+import sys
+from typing import Iterable
+
+import torch
+
+import util.lr_sched as lr_sched
+import util.misc as misc
+
+
+def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer, epoch: int,
+                    loss_scaler, args=None):
+    model.train(True)
+    log = misc.MetricLogger(delimiter="  ")
+    log.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    n_iter = len(data_loader)
+    accum = args.accum_iter
+    optimizer.zero_grad()
+
+    for it, data in enumerate(log.log_every(data_loader, n_iter // 4, f"Epoch: [{epoch}]")):
+        boundary_start = it % accum == 0
+        boundary_end = (it + 1) % accum == 0
+        if boundary_start:
+            lr_sched.adjust_learning_rate(optimizer, it / n_iter + epoch, args)
+
+        vqa_loss, vaq_loss, qav_loss = model(data)
+        loss = vqa_loss + vaq_loss + qav_loss
+        vals = torch.stack([vqa_loss.reshape(()).float(), vaq_loss.reshape(()).float(),
+                            qav_loss.reshape(()).float()]).tolist()       # one D2H copy (it also syncs)
+        loss_value = vals[0] + vals[1] + vals[2]
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+
+        loss_scaler(loss / accum, optimizer, parameters=model.parameters(), update_grad=boundary_end)
+        if boundary_end:
+            optimizer.zero_grad()
+
+        log.update(loss=loss_value, vqa_loss=vals[0], vaq_loss=vals[1], qav_loss=vals[2])
+        log.update(lr=optimizer.param_groups[0]["lr"])
+        if getattr(args, "debug", False):
+            break
+
+    log.synchronize_between_processes()
+    print("Averaged stats:", log)
+    return {k: m.global_avg for k, m in log.meters.items()}

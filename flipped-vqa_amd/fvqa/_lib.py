@@ -1,0 +1,93 @@
+"""ctypes binding of libfvqa_hip.so (include/fvqa.h). No torch types cross this boundary:
+only raw device pointers, sizes and a hipStream_t.
+
+The product path has NO fallback: if the library is missing or does not export a declared
+symbol, importing / calling raises FvqaLibraryError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_RESIDUAL = 0, 1
+ABI_VERSION = 1
+
+_p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+
+# name -> (restype, argtypes); must list every entry point of include/fvqa.h
+SIGNATURES = {
+    "fvqa_version": (_i, []),
+    "fvqa_arch": (C.c_char_p, []),
+    "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
+    "fvqa_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fvqa_rope_qk": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_swiglu_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "fvqa_swiglu_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "fvqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_attn_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "fvqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_visual_proj_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "fvqa_visual_proj_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "fvqa_embed_splice": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_splice_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_ce_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i64, _p]),
+    "fvqa_ce_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i64, _i, _p]),
+    "fvqa_qav_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "fvqa_qav_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "fvqa_grad_norm_workspace": (_sz, [_i]),
+    "fvqa_grad_unscale_norm": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "fvqa_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p]),
+    "fvqa_scaler_update": (_i, [_p, _p, _p, _p, _f, _f, _i, _p]),
+    "fvqa_cast_rows": (_i, [_p, _p, _i, _i, _i, _p]),
+}
+
+ERRORS = {-1: "FVQA_EINVAL (null pointer / bad enum)", -2: "FVQA_ESHAPE (unsupported dimension)",
+          -3: "FVQA_EALIGN (misaligned pointer / short workspace)"}
+
+
+class FvqaLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get("FVQA_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfvqa_hip.so"))
+
+
+_LIB: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and bind every symbol of include/fvqa.h; raises if anything is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FvqaLibraryError(
+            f"{path} not found: build it with `python -m fvqa.build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU or PyTorch fallback for the Flipped-VQA hot path.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise FvqaLibraryError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise FvqaLibraryError(f"{path} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.fvqa_version()
+    if v != ABI_VERSION:
+        raise FvqaLibraryError(f"{path}: ABI version {v}, host expects {ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = ERRORS.get(rc, f"hipError_t {-(rc + 1000)}" if rc <= -1000 else str(rc))
+        raise RuntimeError(f"{what} failed: {msg}")

@@ -1,0 +1,349 @@
+"""Tensor-level wrappers over the C ABI (include/fvqa.h): each function validates shapes, dtypes,
+contiguity and device ON THE HOST before a kernel is launched (a mis-shaped operand must raise
+here, never fault on the GPU), then passes raw device pointers + the current HIP stream.
+
+PyTorch is only the owner of device memory and streams here; all arithmetic is in libfvqa_hip.so.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_NONE, EPI_RESIDUAL, F32
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DTN = {torch.float32: "f32", torch.bfloat16: "bf16"}
+
+# bench.py sets this to a list to collect (start_event, end_event, flops, kernel_key) per GEMM launch
+GEMM_TIMING = None
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"storage dtype must be float32 or bfloat16, got {dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ValueError("fvqa ops need device tensors (no CPU fallback exists)")
+        if not t.is_contiguous():
+            raise ValueError("fvqa ops need contiguous tensors")
+        dev = dev or t.device
+        if t.device != dev:
+            raise ValueError("tensors on different devices")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(cond: bool, msg: str):
+    if not cond:
+        raise ValueError(msg)
+
+
+# ------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
+            tail: Optional[torch.Tensor] = None, m_split: int = 0, variant: int = 0) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ b[N,K]^T (+ residual). Rows >= m_split go to `tail` (fp32) when given."""
+    _dev(a, b, out, residual, tail)
+    _need(a.dim() == 2 and b.dim() == 2 and out.dim() == 2, "gemm_nt: 2-D operands")
+    M, K = a.shape
+    N, K2 = b.shape
+    _need(K == K2, f"gemm_nt: K mismatch {K} vs {K2}")
+    _need(a.dtype == b.dtype, "gemm_nt: a/b dtype mismatch")
+    _need(out.dtype in (a.dtype, torch.float32), "gemm_nt: out dtype")
+    if tail is None:
+        _need(tuple(out.shape) == (M, N), f"gemm_nt: out shape {tuple(out.shape)} != {(M, N)}")
+        m_split = M
+    else:
+        _need(0 <= m_split <= M, "gemm_nt: m_split")
+        _need(out.shape[0] >= m_split and out.shape[1] == N, "gemm_nt: out too small")
+        _need(tail.dtype == torch.float32 and tuple(tail.shape) == (M - m_split, N), "gemm_nt: tail shape")
+    epi = EPI_NONE
+    if residual is not None:
+        _need(residual.dtype == a.dtype and out.dtype == a.dtype, "gemm_nt: residual dtype")
+        _need(residual.shape[1] == N and residual.shape[0] >= min(M, m_split), "gemm_nt: residual shape")
+        epi = EPI_RESIDUAL
+    lib = _lib.load()
+    timing = GEMM_TIMING
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), _ptr(out), _ptr(residual), _ptr(tail), M, N, K, K, K, N, m_split,
+                          dt_code(a.dtype), dt_code(out.dtype), epi, variant, _stream())
+    if timing is not None:
+        e1.record()
+        key = f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_{'res' if epi else 'none'}"
+        timing.append((e0, e1, 2.0 * M * N * K, key))
+    _lib.check(rc, "fvqa_gemm_nt")
+    return out
+
+
+# ------------------------------------------------------------------------------------ row ops
+def rmsnorm_fwd(x, w, y, rstd, eps: float, rows: Optional[int] = None):
+    _dev(x, w, y, rstd)
+    dim = x.shape[-1]
+    rows = rows if rows is not None else x.numel() // dim
+    _need(x.dtype == w.dtype == y.dtype, "rmsnorm_fwd: dtype")
+    _need(w.numel() == dim and y.shape[-1] == dim, "rmsnorm_fwd: dim")
+    _need(x.numel() >= rows * dim and y.numel() >= rows * dim, "rmsnorm_fwd: rows")
+    _need(rstd is None or (rstd.dtype == torch.float32 and rstd.numel() >= rows), "rmsnorm_fwd: rstd")
+    rc = _lib.load().fvqa_rmsnorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(rstd), rows, dim, float(eps),
+                                      dt_code(x.dtype), _stream())
+    _lib.check(rc, "fvqa_rmsnorm_fwd")
+    return y
+
+
+def rmsnorm_bwd(g, x, w, rstd, dx, resid=None, rows: Optional[int] = None):
+    _dev(g, x, w, rstd, dx, resid)
+    dim = x.shape[-1]
+    rows = rows if rows is not None else x.numel() // dim
+    _need(g.dtype == x.dtype == w.dtype == dx.dtype, "rmsnorm_bwd: dtype")
+    _need(resid is None or resid.dtype == x.dtype, "rmsnorm_bwd: resid dtype")
+    for t in (g, x, dx, resid):
+        _need(t is None or (t.shape[-1] == dim and t.numel() >= rows * dim), "rmsnorm_bwd: shape")
+    _need(rstd.dtype == torch.float32 and rstd.numel() >= rows and w.numel() == dim, "rmsnorm_bwd: rstd/w")
+    rc = _lib.load().fvqa_rmsnorm_bwd(_ptr(g), _ptr(x), _ptr(w), _ptr(rstd), _ptr(resid), _ptr(dx), rows, dim,
+                                      dt_code(x.dtype), _stream())
+    _lib.check(rc, "fvqa_rmsnorm_bwd")
+    return dx
+
+
+def rope_qk(qkv, cos_t, sin_t, n_seq: int, seq_len: int, n_heads: int, head_dim: int, inverse: bool = False):
+    _dev(qkv, cos_t, sin_t)
+    dim = n_heads * head_dim
+    _need(qkv.shape[-1] == 3 * dim and qkv.numel() >= n_seq * seq_len * 3 * dim, "rope_qk: qkv shape")
+    _need(cos_t.dtype == sin_t.dtype == torch.float32, "rope_qk: table dtype")
+    _need(cos_t.shape[-1] == head_dim // 2 and cos_t.shape[0] >= seq_len and sin_t.shape == cos_t.shape,
+          "rope_qk: table shape")
+    rc = _lib.load().fvqa_rope_qk(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), n_seq, seq_len, n_heads, head_dim,
+                                  int(inverse), dt_code(qkv.dtype), _stream())
+    _lib.check(rc, "fvqa_rope_qk")
+    return qkv
+
+
+def swiglu_fwd(ab, z, rows: int, hidden: int):
+    _dev(ab, z)
+    _need(ab.dtype == z.dtype, "swiglu_fwd: dtype")
+    _need(ab.numel() >= rows * 2 * hidden and z.numel() >= rows * hidden, "swiglu_fwd: shape")
+    rc = _lib.load().fvqa_swiglu_fwd(_ptr(ab), _ptr(z), rows, hidden, dt_code(ab.dtype), _stream())
+    _lib.check(rc, "fvqa_swiglu_fwd")
+    return z
+
+
+def swiglu_bwd(dz, ab, dab, rows: int, hidden: int):
+    _dev(dz, ab, dab)
+    _need(dz.dtype == ab.dtype == dab.dtype, "swiglu_bwd: dtype")
+    _need(ab.numel() >= rows * 2 * hidden and dab.numel() >= rows * 2 * hidden and dz.numel() >= rows * hidden,
+          "swiglu_bwd: shape")
+    rc = _lib.load().fvqa_swiglu_bwd(_ptr(dz), _ptr(ab), _ptr(dab), rows, hidden, dt_code(ab.dtype), _stream())
+    _lib.check(rc, "fvqa_swiglu_bwd")
+    return dab
+
+
+def cast_rows(src, dst_rows):
+    """dst_rows (n, dim) storage dtype <- src (n, dim) fp32."""
+    _dev(src, dst_rows)
+    _need(src.dtype == torch.float32 and src.shape == dst_rows.shape and src.dim() == 2, "cast_rows: shape")
+    rc = _lib.load().fvqa_cast_rows(_ptr(src), _ptr(dst_rows), src.shape[0], src.shape[1],
+                                    dt_code(dst_rows.dtype), _stream())
+    _lib.check(rc, "fvqa_cast_rows")
+    return dst_rows
+
+
+# ------------------------------------------------------------------------------------ attention
+def _attn_shapes(qkv, n_seq, S, H, Dh, A):
+    D = H * Dh
+    _need(qkv.dim() == 2 and tuple(qkv.shape) == (n_seq * S + A, 3 * D),
+          f"attention: qkv must be ({n_seq * S + A}, {3 * D}), got {tuple(qkv.shape)}")
+    _need(Dh == 128 and 1 <= A <= 16, "attention: head_dim must be 128 and adapter_len <= 16")
+    return D
+
+
+def attn_fwd(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, Dh, A, F):
+    _dev(qkv, o, lse_a, lse_t, gate1, gate2, vstart)
+    D = _attn_shapes(qkv, n_seq, S, H, Dh, A)
+    _need(o.dtype == qkv.dtype and tuple(o.shape) == (n_seq * S, D), "attn_fwd: o shape")
+    for t in (lse_a, lse_t):
+        _need(t.dtype == torch.float32 and t.numel() == n_seq * H * S, "attn_fwd: lse shape")
+    for t in (gate1, gate2):
+        _need(t.dtype == torch.float32 and t.numel() == H, "attn_fwd: gate shape")
+    _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "attn_fwd: vstart")
+    rc = _lib.load().fvqa_attn_fwd(_ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1), _ptr(gate2),
+                                   _ptr(vstart), n_seq, S, H, Dh, A, F, dt_code(qkv.dtype), _stream())
+    _lib.check(rc, "fvqa_attn_fwd")
+    return o
+
+
+def attn_bwd_workspace(n_seq, S, H, Dh, A) -> int:
+    return int(_lib.load().fvqa_attn_bwd_workspace(n_seq, S, H, Dh, A))
+
+
+def attn_bwd(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace,
+             n_seq, S, H, Dh, A, F):
+    _dev(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace)
+    D = _attn_shapes(qkv, n_seq, S, H, Dh, A)
+    _need(dqkv.dtype == qkv.dtype and dqkv.shape == qkv.shape, "attn_bwd: dqkv shape")
+    for t in (d_o, o):
+        _need(t.dtype == qkv.dtype and tuple(t.shape) == (n_seq * S, D), "attn_bwd: o/d_o shape")
+    for t in (lse_a, lse_t):
+        _need(t.dtype == torch.float32 and t.numel() == n_seq * H * S, "attn_bwd: lse shape")
+    for t in (gate1, gate2, dgate1, dgate2):
+        _need(t.dtype == torch.float32 and t.numel() == H, "attn_bwd: gate shape")
+    _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "attn_bwd: vstart")
+    wbytes = workspace.numel() * workspace.element_size()
+    _need(wbytes >= attn_bwd_workspace(n_seq, S, H, Dh, A), "attn_bwd: workspace too small")
+    rc = _lib.load().fvqa_attn_bwd(_ptr(d_o), _ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1),
+                                   _ptr(gate2), _ptr(vstart), _ptr(dqkv), _ptr(dgate1), _ptr(dgate2),
+                                   _ptr(workspace), wbytes, n_seq, S, H, Dh, A, F, dt_code(qkv.dtype), _stream())
+    _lib.check(rc, "fvqa_attn_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------ heads / splice
+def visual_proj_fwd(video, W, temporal, vf_raw, vf_tok):
+    _dev(video, W, temporal, vf_raw, vf_tok)
+    R, K = video.shape
+    D = W.shape[0]
+    F = temporal.shape[0]
+    _need(video.dtype == W.dtype == temporal.dtype == vf_raw.dtype == torch.float32, "visual_proj_fwd: fp32")
+    _need(W.shape[1] == K and temporal.shape[1] == D and R % F == 0, "visual_proj_fwd: shapes")
+    _need(tuple(vf_raw.shape) == (R, D) and tuple(vf_tok.shape) == (R, D), "visual_proj_fwd: out shapes")
+    rc = _lib.load().fvqa_visual_proj_fwd(_ptr(video), _ptr(W), _ptr(temporal), _ptr(vf_raw), _ptr(vf_tok), R, F,
+                                          K, D, dt_code(vf_tok.dtype), _stream())
+    _lib.check(rc, "fvqa_visual_proj_fwd")
+
+
+def visual_proj_bwd(d_tok, d_qav, video, dW, dtemporal):
+    _dev(d_tok, d_qav, video, dW, dtemporal)
+    R, K = video.shape
+    D = dW.shape[0]
+    F = dtemporal.shape[0]
+    for t in (d_tok, d_qav):
+        _need(t is None or (t.dtype == torch.float32 and tuple(t.shape) == (R, D)), "visual_proj_bwd: d_tok/d_qav")
+    _need(dW.dtype == dtemporal.dtype == video.dtype == torch.float32, "visual_proj_bwd: fp32")
+    _need(tuple(dW.shape) == (D, K) and tuple(dtemporal.shape) == (F, D) and R % F == 0, "visual_proj_bwd: shapes")
+    rc = _lib.load().fvqa_visual_proj_bwd(_ptr(d_tok), _ptr(d_qav), _ptr(video), _ptr(dW), _ptr(dtemporal), R, F,
+                                          K, D, _stream())
+    _lib.check(rc, "fvqa_visual_proj_bwd")
+
+
+def embed_splice(ids, emb, vf_tok, h, n_seq, S, F, *, vstart: int = 0, zero_labels=None, index=None, mode: int = 0):
+    _dev(ids, emb, vf_tok, h, zero_labels, index)
+    D = emb.shape[1]
+    _need(ids.dtype == torch.int64 and ids.numel() == n_seq * S, "embed_splice: ids")
+    _need(emb.dtype == vf_tok.dtype == h.dtype, "embed_splice: dtype")
+    _need(vf_tok.numel() == n_seq * F * D and h.numel() >= n_seq * S * D and h.shape[-1] == D, "embed_splice: shapes")
+    _need(zero_labels is None or (zero_labels.dtype == torch.int64 and zero_labels.numel() == n_seq * S),
+          "embed_splice: zero_labels")
+    _need(index is None or (index.dtype == torch.int64 and index.numel() == n_seq * F), "embed_splice: index")
+    # ids must address the table: checked on the host copy by the caller (see model.py)
+    rc = _lib.load().fvqa_embed_splice(_ptr(ids), _ptr(emb), _ptr(vf_tok), _ptr(zero_labels), _ptr(index), _ptr(h),
+                                       n_seq, S, D, F, vstart, mode, dt_code(h.dtype), _stream())
+    _lib.check(rc, "fvqa_embed_splice")
+    return h
+
+
+def splice_bwd(dh, d_tok, n_seq, S, F, *, vstart: int = 0, index=None, mode: int = 0):
+    _dev(dh, d_tok, index)
+    D = dh.shape[-1]
+    _need(dh.numel() >= n_seq * S * D, "splice_bwd: dh")
+    _need(d_tok.dtype == torch.float32 and d_tok.numel() == n_seq * F * D, "splice_bwd: d_tok")
+    _need(index is None or (index.dtype == torch.int64 and index.numel() == n_seq * F), "splice_bwd: index")
+    rc = _lib.load().fvqa_splice_bwd(_ptr(dh), _ptr(index), _ptr(d_tok), n_seq, S, D, F, vstart, mode,
+                                     dt_code(dh.dtype), _stream())
+    _lib.check(rc, "fvqa_splice_bwd")
+
+
+def ce_fwd(logits, labels, lse, rowloss, loss_sum, n_seq, S, V, ignore_index: int):
+    _dev(logits, labels, lse, rowloss, loss_sum)
+    _need(logits.dtype == torch.float32 and logits.numel() == n_seq * S * V, "ce_fwd: logits")
+    _need(labels.dtype == torch.int64 and labels.numel() == n_seq * S, "ce_fwd: labels")
+    for t in (lse, rowloss):
+        _need(t.dtype == torch.float32 and t.numel() >= n_seq * S, "ce_fwd: lse/rowloss")
+    _need(loss_sum.dtype == torch.float32 and loss_sum.numel() >= 2, "ce_fwd: loss_sum")
+    rc = _lib.load().fvqa_ce_fwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(rowloss), _ptr(loss_sum), n_seq, S, V,
+                                 ignore_index, _stream())
+    _lib.check(rc, "fvqa_ce_fwd")
+
+
+def ce_bwd(logits, labels, lse, loss_sum, gscale, dlogits, n_seq, S, V, ignore_index: int):
+    _dev(logits, labels, lse, loss_sum, gscale, dlogits)
+    _need(logits.dtype == torch.float32 and logits.numel() == n_seq * S * V, "ce_bwd: logits")
+    _need(dlogits.numel() == n_seq * S * V, "ce_bwd: dlogits")
+    _need(labels.dtype == torch.int64 and labels.numel() == n_seq * S, "ce_bwd: labels")
+    _need(gscale.dtype == torch.float32 and gscale.numel() >= 1 and loss_sum.numel() >= 2, "ce_bwd: scalars")
+    rc = _lib.load().fvqa_ce_bwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss_sum), _ptr(gscale), _ptr(dlogits),
+                                 n_seq, S, V, ignore_index, dt_code(dlogits.dtype), _stream())
+    _lib.check(rc, "fvqa_ce_bwd")
+
+
+def qav_head_fwd(xn, vf_raw, labels, probs, rowloss, loss_sum, n_seq, S, D, F, tau: float):
+    _dev(xn, vf_raw, labels, probs, rowloss, loss_sum)
+    _need(xn.numel() >= n_seq * S * D and xn.shape[-1] == D, "qav_head_fwd: xn")
+    _need(vf_raw.dtype == torch.float32 and vf_raw.numel() == n_seq * F * D, "qav_head_fwd: vf_raw")
+    _need(labels.dtype == torch.int64 and labels.numel() == n_seq * S, "qav_head_fwd: labels")
+    _need(probs.dtype == torch.float32 and probs.numel() >= n_seq * S * F, "qav_head_fwd: probs")
+    _need(rowloss.dtype == torch.float32 and rowloss.numel() >= n_seq * S, "qav_head_fwd: rowloss")
+    rc = _lib.load().fvqa_qav_head_fwd(_ptr(xn), _ptr(vf_raw), _ptr(labels), _ptr(probs), _ptr(rowloss),
+                                       _ptr(loss_sum), n_seq, S, D, F, float(tau), dt_code(xn.dtype), _stream())
+    _lib.check(rc, "fvqa_qav_head_fwd")
+
+
+def qav_head_bwd(xn, vf_raw, labels, probs, loss_sum, gscale, dxn, d_raw, n_seq, S, D, F, tau: float):
+    _dev(xn, vf_raw, labels, probs, loss_sum, gscale, dxn, d_raw)
+    _need(xn.numel() >= n_seq * S * D and dxn.numel() >= n_seq * S * D and dxn.dtype == xn.dtype, "qav_head_bwd: xn")
+    _need(vf_raw.numel() == n_seq * F * D and d_raw.dtype == torch.float32 and d_raw.numel() == n_seq * F * D,
+          "qav_head_bwd: vf")
+    _need(labels.dtype == torch.int64 and labels.numel() == n_seq * S, "qav_head_bwd: labels")
+    rc = _lib.load().fvqa_qav_head_bwd(_ptr(xn), _ptr(vf_raw), _ptr(labels), _ptr(probs), _ptr(loss_sum),
+                                       _ptr(gscale), _ptr(dxn), _ptr(d_raw), n_seq, S, D, F, float(tau),
+                                       dt_code(xn.dtype), _stream())
+    _lib.check(rc, "fvqa_qav_head_bwd")
+
+
+# ------------------------------------------------------------------------------------ optimizer
+def grad_norm_workspace(n_seg: int) -> int:
+    return int(_lib.load().fvqa_grad_norm_workspace(n_seg))
+
+
+def grad_unscale_norm(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace):
+    _dev(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace)
+    n_seg = seg_off.numel() - 1
+    _need(grad.dtype == torch.float32 and seg_off.dtype == torch.int64 and n_seg >= 1, "grad_unscale_norm: types")
+    _need(seg_sq.numel() >= n_seg and seg_sq.dtype == torch.float32, "grad_unscale_norm: seg_sq")
+    wbytes = workspace.numel() * workspace.element_size()
+    rc = _lib.load().fvqa_grad_unscale_norm(_ptr(grad), _ptr(seg_off), n_seg, _ptr(scale), _ptr(seg_sq),
+                                            _ptr(found_inf), _ptr(total_norm), _ptr(workspace), wbytes, _stream())
+    _lib.check(rc, "fvqa_grad_unscale_norm")
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, found_inf=None):
+    _dev(param, grad, exp_avg, exp_avg_sq, step, found_inf)
+    n = param.numel()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        _need(t.dtype == torch.float32 and t.numel() == n, "adamw_step: fp32 tensors of equal size")
+    rc = _lib.load().fvqa_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), n, float(lr),
+                                     float(beta1), float(beta2), float(eps), float(weight_decay), _ptr(step),
+                                     _ptr(found_inf), _stream())
+    _lib.check(rc, "fvqa_adamw_step")
+
+
+def scaler_update(step, scale, tracker, found_inf, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+    _dev(step, scale, tracker, found_inf)
+    rc = _lib.load().fvqa_scaler_update(_ptr(step), _ptr(scale), _ptr(tracker), _ptr(found_inf),
+                                        float(growth_factor), float(backoff_factor), int(growth_interval), _stream())
+    _lib.check(rc, "fvqa_scaler_update")

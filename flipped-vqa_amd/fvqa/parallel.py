@@ -1,0 +1,54 @@
+"""Data-parallel training over one 8xMI355X node: replicated model, samples sharded by rank,
+ONE exchange step — an all-reduce(mean) of the flat fp32 trainable-gradient buffer (18 MB for 7B)
+over RCCL/xGMI per optimizer step. Replaces torch DDP of reference train.py:115-117, whose bucketed
+reducer all-reduces the same ~4.5 M scalars on every backward.
+
+The averaging rule is backend-agnostic (tests drive it with gloo on CPU tensors)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def allreduce_mean_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place mean over ranks of one flat gradient buffer (what DDP computes per bucket)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grad
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat_grad
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    flat_grad.div_(world)
+    return flat_grad
+
+
+def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0):
+    """DistributedSampler's rule (reference dataloader/__init__.py:19-21): permute with seed+epoch,
+    pad by wrapping to a multiple of world, take rank::world."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n_items, generator=g).tolist()
+    else:
+        idx = list(range(n_items))
+    total = ((n_items + world - 1) // world) * world
+    idx += idx[: total - len(idx)]
+    return idx[rank:total:world]
+
+
+class DataParallel(torch.nn.Module):
+    """Minimal DDP stand-in: exposes `.module`, forwards calls, and synchronises gradients through
+    `sync_grads()` (invoked by the loss scaler right before unscale/step on accumulation
+    boundaries — mathematically identical to DDP's every-backward all-reduce)."""
+
+    def __init__(self, module, group=None):
+        super().__init__()
+        self.module = module
+        self.group = group
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def sync_grads(self):
+        flat = self.module.flat_params()
+        allreduce_mean_(flat.flat_grad, self.group)

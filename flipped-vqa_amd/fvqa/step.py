@@ -1,0 +1,370 @@
+"""The Flipped-VQA training step on MI355X: forward + backward of reference
+llama/model.py:254-365 as an explicit schedule of libfvqa_hip.so kernels.
+
+Design (MI355X-first, not a port of the reference's autograd graph):
+  * the 1..3 flipped streams (vqa / vaq / qav) share every frozen weight, so they are batched
+    into ONE set of n_streams*B sequences: each weight panel is read once per layer per pass and
+    the projection GEMMs see M = n_streams*B*S rows (+A adapter rows that ride along);
+  * frozen weights are packed once: Wq|Wk|Wv and W1|W3 row-concatenated, plus a TRANSPOSED copy of
+    every frozen matrix (288 GB of HBM3E makes 2x weights cheap) so that dX = dY·W is the same
+    K-contiguous NT GEMM as the forward — one kernel family, no transposed LDS reads;
+  * activations needed by the backward live in a preallocated arena (no allocator traffic);
+  * all trainables (adapter queries, gates, visual projection, temporal embedding) are views of
+    one flat fp32 buffer, and so are their gradients: the backward accumulates straight into the
+    flat gradient buffer, which is what RCCL all-reduces and what the fused optimizer consumes.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+TASKS = ("vqa", "vaq", "qav")
+
+
+class FrozenPack:
+    """Fused + transposed device copies of the frozen LLaMA weights (storage dtype)."""
+
+    def __init__(self, model, layer_ids: List[int]):
+        self.layer_ids = layer_ids
+        self.wqkv, self.wqkv_t, self.wo, self.wo_t = [], [], [], []
+        self.w13, self.w13_t, self.w2, self.w2_t = [], [], [], []
+        self.an, self.fn = [], []
+        for li in layer_ids:
+            blk = model.layers[li]
+            att, ff = blk.attention, blk.feed_forward
+            dt = att.wq.weight.dtype
+            wqkv = torch.cat([att.wq.weight.data, att.wk.weight.data, att.wv.weight.data], 0).contiguous()
+            D = att.wq.weight.shape[0]
+            # parameters become views of the fused buffer: no second copy of the originals
+            att.wq.weight.data = wqkv[0:D]
+            att.wk.weight.data = wqkv[D:2 * D]
+            att.wv.weight.data = wqkv[2 * D:3 * D]
+            w13 = torch.cat([ff.w1.weight.data, ff.w3.weight.data], 0).contiguous()
+            Hf = ff.w1.weight.shape[0]
+            ff.w1.weight.data = w13[0:Hf]
+            ff.w3.weight.data = w13[Hf:2 * Hf]
+            self.wqkv.append(wqkv)
+            self.wqkv_t.append(wqkv.t().contiguous())
+            self.wo.append(att.wo.weight.data)
+            self.wo_t.append(att.wo.weight.data.t().contiguous())
+            self.w13.append(w13)
+            self.w13_t.append(w13.t().contiguous())
+            self.w2.append(ff.w2.weight.data)
+            self.w2_t.append(ff.w2.weight.data.t().contiguous())
+            self.an.append(blk.attention_norm.weight.data)
+            self.fn.append(blk.ffn_norm.weight.data)
+            assert dt == wqkv.dtype
+        self.norm = model.norm.weight.data
+        self.emb = model.tok_embeddings.weight.data
+        self.wout = model.output.weight.data
+        self.wout_t = model.output.weight.data.t().contiguous()
+
+
+class Arena:
+    """Activation + scratch buffers for one (n_seq, S) geometry."""
+
+    def __init__(self, eng: "StepEngine", n_seq: int, S: int, n_lm: int):
+        c = eng
+        dev, dt = c.device, c.dtype
+        L, D, Hf, H, A, V = c.L, c.D, c.Hf, c.H, c.A, c.V
+        R = n_seq * S
+        Ra = R + A
+        f32 = torch.float32
+        e = lambda *s, dtype=dt: torch.empty(*s, dtype=dtype, device=dev)  # noqa: E731
+        self.n_seq, self.S, self.R, self.Ra = n_seq, S, R, Ra
+        self.xs = e(L + 1, R, D)
+        self.rstd1 = e(L, R, dtype=f32)
+        self.rstd2 = e(L, R, dtype=f32)
+        self.qkv = e(L, Ra, 3 * D)
+        self.o = e(L, R, D)
+        self.lse_a = e(L, n_seq * H * S, dtype=f32)
+        self.lse_t = e(L, n_seq * H * S, dtype=f32)
+        self.h = e(L, R, D)
+        self.ab = e(L, R, 2 * Hf)
+        self.xn = e(Ra, D)
+        self.hn = e(R, D)
+        self.z = e(R, Hf)
+        self.xnf = e(R, D)
+        self.rstdN = e(R, dtype=f32)
+        self.n_lm = n_lm                        # sequences scored by the LM head (vqa [+ vaq])
+        self.logits = e(n_lm * S, V, dtype=f32)
+        self.lse = e(R, dtype=f32)
+        self.rowloss = e(R, dtype=f32)
+        self.probs = e(R * c.F, dtype=f32)
+        self.loss_sum = torch.zeros(3, 2, dtype=f32, device=dev)
+        # backward scratch
+        self.dlogits = e(n_lm * S, V)
+        self.dxnf = e(R, D)
+        self.da = e(R, D)
+        self.db = e(R, D)
+        self.dz = e(R, Hf)
+        self.dab = e(R, 2 * Hf)
+        self.dhn = e(R, D)
+        self.dh = e(R, D)
+        self.do = e(R, D)
+        self.dqkv = e(Ra, 3 * D)
+        self.dxn = e(R, D)
+        self.d_tok = e(eng_frames(c, n_seq), D, dtype=f32)
+        self.d_qav = e(eng_frames(c, n_seq), D, dtype=f32)
+        self.gscale = e(3, dtype=f32)
+        ws = ops.attn_bwd_workspace(n_seq, S, H, c.Dh, A)
+        self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=dev)
+
+
+def eng_frames(c, n_seq):
+    return (n_seq // c.n_streams) * c.F
+
+
+class StepEngine:
+    def __init__(self, model):
+        p = model.params
+        self.model = model
+        self.D, self.H = p.dim, p.n_heads
+        self.Dh = p.dim // p.n_heads
+        self.V = model.vocab_size
+        self.A, self.F = model.adapter_len, model.max_feats
+        self.eps = p.norm_eps
+        self.tau = float(model.tau)
+        self.layer_ids = list(range(p.n_layers))[-model.adapter_layer:]
+        self.L = len(self.layer_ids)
+        self.Hf = model.layers[0].feed_forward.w1.weight.shape[0]
+        self.tasks = ["vqa"] + (["vaq"] if model.args.vaq else []) + (["qav"] if model.args.qav else [])
+        self.n_streams = len(self.tasks)
+        self.device = model.tok_embeddings.weight.device
+        self.dtype = model.tok_embeddings.weight.dtype
+        if self.device.type != "cuda":
+            raise RuntimeError("Flipped-VQA hot path runs only on a ROCm device (no CPU fallback); "
+                               "move the model with model.to('cuda') first")
+        if self.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"frozen weights must be float32 or bfloat16, got {self.dtype}")
+        self.pack = FrozenPack(model, self.layer_ids)
+        cos, sin = model.rope_tables()
+        self.cos = cos.to(self.device).contiguous()
+        self.sin = sin.to(self.device).contiguous()
+        self._arena: Dict[tuple, Arena] = {}
+        self._vstart: Dict[tuple, torch.Tensor] = {}
+        self.saved = None
+        self.keep_logits = False
+
+    # ------------------------------------------------------------------ helpers
+    def arena(self, n_seq, S) -> Arena:
+        key = (n_seq, S)
+        if key not in self._arena:
+            n_lm = (n_seq // self.n_streams) * (1 + int("vaq" in self.tasks))
+            self._arena[key] = Arena(self, n_seq, S, n_lm)
+        return self._arena[key]
+
+    def vstart_tensor(self, B, vs_vqa, vs_vaq) -> torch.Tensor:
+        key = (B, vs_vqa, vs_vaq)
+        if key not in self._vstart:
+            v = []
+            for t in self.tasks:
+                v += [{"vqa": vs_vqa, "vaq": vs_vaq, "qav": -1}[t]] * B
+            self._vstart[key] = torch.tensor(v, dtype=torch.int32, device=self.device)
+        return self._vstart[key]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data: dict):
+        m, pk = self.model, self.pack
+        dev = self.device
+        F, D, V, A, H, Dh, Hf, L = self.F, self.D, self.V, self.A, self.H, self.Dh, self.Hf, self.L
+        video = data["video"]
+        B = video.shape[0]
+        S = data["text_id"]["vqa"].shape[-1]
+        n_opt = data["text_id"]["vqa"].shape[1]
+        if n_opt != 1:
+            raise ValueError("training path expects n_options == 1 (reference llama/model.py:267)")
+        vs = {"vqa": int(data["video_start"]["vqa"][0]), "vaq": int(data["video_start"]["vaq"][0])}
+        for t in ("vqa", "vaq"):
+            if t in self.tasks and not (0 <= vs[t] and vs[t] + F <= S):
+                raise ValueError(f"video_start[{t}]={vs[t]} does not leave room for {F} frames in S={S}")
+        ids_h = {t: data["text_id"][t].reshape(B, S) for t in self.tasks}
+        for t, v in ids_h.items():                              # host-side range check before the gather
+            if not v.is_cuda and (int(v.min()) < 0 or int(v.max()) >= V):
+                raise ValueError(f"text_id[{t}] outside [0, {V})")
+        ids = {t: v.to(dev, non_blocking=True).contiguous() for t, v in ids_h.items()}
+        labels = {t: data["label"][t].reshape(B, S).to(dev, non_blocking=True).contiguous() for t in self.tasks}
+        video_d = video.to(dev, dtype=torch.float32, non_blocking=True).reshape(B * F, -1).contiguous()
+        qidx = None
+        if "qav" in self.tasks:
+            qi = data["video_index"]["qav"]
+            if not qi.is_cuda and (int(qi.min()) < 0 or int(qi.max()) >= S):
+                raise ValueError("video_index[qav] outside the sequence")
+            qidx = qi.to(dev, non_blocking=True).contiguous()
+
+        n_seq = self.n_streams * B
+        ar = self.arena(n_seq, S)
+        R, Ra = ar.R, ar.Ra
+        vstart = self.vstart_tensor(B, vs["vqa"], vs["vaq"])
+
+        # visual projection + temporal embedding (model.py:322,324)
+        vf_raw = torch.empty(B * F, D, dtype=torch.float32, device=dev)
+        vf_tok = torch.empty(B * F, D, dtype=self.dtype, device=dev)
+        ops.visual_proj_fwd(video_d, m.visual_proj.weight.data, m.temporal_emb.weight.data, vf_raw, vf_tok)
+
+        # embedding gather + splice per stream (model.py:286-294,326-336)
+        for k, t in enumerate(self.tasks):
+            h0 = ar.xs[0][k * B * S:(k + 1) * B * S]
+            if t == "qav":
+                ops.embed_splice(ids[t], pk.emb, vf_tok, h0, B, S, F, zero_labels=labels[t], index=qidx, mode=1)
+            else:
+                ops.embed_splice(ids[t], pk.emb, vf_tok, h0, B, S, F, vstart=vs[t], mode=0)
+
+        adapter = m.adapter_query.weight.data.view(-1, A, D)     # (adapter_layer, A, D); model.py:304
+        for i in range(L):
+            x = ar.xs[i]
+            ops.rmsnorm_fwd(x, pk.an[i], ar.xn, ar.rstd1[i], self.eps, rows=R)
+            ops.cast_rows(adapter[i], ar.xn[R:Ra])
+            ops.gemm_nt(ar.xn, pk.wqkv[i], ar.qkv[i])
+            ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
+            g1, g2 = m.gate_views(i)
+            ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
+            ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)
+            ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
+            ops.gemm_nt(ar.hn, pk.w13[i], ar.ab[i])
+            ops.swiglu_fwd(ar.ab[i], ar.z, R, Hf)
+            ops.gemm_nt(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i])
+
+        ops.rmsnorm_fwd(ar.xs[L], pk.norm, ar.xnf, ar.rstdN, self.eps, rows=R)
+        n_lm = ar.n_lm
+        ops.gemm_nt(ar.xnf[: n_lm * S], pk.wout, ar.logits)
+        ar.loss_sum.zero_()
+        for k, t in enumerate(self.tasks):
+            rows = slice(k * B * S, (k + 1) * B * S)
+            if t == "qav":
+                ops.qav_head_fwd(ar.xnf[rows], vf_raw, labels[t], ar.probs[k * B * S * F:], ar.rowloss[rows],
+                                 ar.loss_sum[2], B, S, D, F, self.tau)
+            else:
+                ops.ce_fwd(ar.logits[rows], labels[t], ar.lse[rows], ar.rowloss[rows], ar.loss_sum[k], B, S, V, 0)
+        self.saved = dict(ar=ar, B=B, S=S, vs=vs, labels=labels, qidx=qidx, video=video_d, vf_raw=vf_raw,
+                          vstart=vstart)
+        losses = ar.loss_sum[:, 0] / ar.loss_sum[:, 1]        # mean over scored rows (NaN if none, as torch CE)
+        return losses
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, g_losses: torch.Tensor, grads: "FlatParams"):
+        """g_losses: (3,) fp32 device tensor = d(total)/d(loss_k). Accumulates into grads.flat_grad."""
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError("backward called without a saved forward")
+        m, pk = self.model, self.pack
+        ar: Arena = sv["ar"]
+        B, S, vs, labels = sv["B"], sv["S"], sv["vs"], sv["labels"]
+        F, D, V, A, H, Dh, Hf, L = self.F, self.D, self.V, self.A, self.H, self.Dh, self.Hf, self.L
+        n_seq, R, Ra = ar.n_seq, ar.R, ar.Ra
+        ar.gscale.copy_(g_losses)
+        ar.d_tok.zero_()
+        has_qav = "qav" in self.tasks
+        if has_qav:
+            ar.d_qav.zero_()
+        for k, t in enumerate(self.tasks):
+            rows = slice(k * B * S, (k + 1) * B * S)
+            if t == "qav":
+                ops.qav_head_bwd(ar.xnf[rows], sv["vf_raw"], labels[t], ar.probs[k * B * S * F:], ar.loss_sum[2],
+                                 ar.gscale[2:3], ar.dxnf[rows], ar.d_qav, B, S, D, F, self.tau)
+            else:
+                ops.ce_bwd(ar.logits[rows], labels[t], ar.lse[rows], ar.loss_sum[k], ar.gscale[k:k + 1],
+                           ar.dlogits[rows], B, S, V, 0)
+        ops.gemm_nt(ar.dlogits, pk.wout_t, ar.dxnf[: ar.n_lm * S])
+        cur, nxt = ar.da, ar.db
+        ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
+        g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
+        for i in reversed(range(L)):
+            ops.gemm_nt(cur, pk.w2_t[i], ar.dz)
+            ops.swiglu_bwd(ar.dz, ar.ab[i], ar.dab, R, Hf)
+            ops.gemm_nt(ar.dab, pk.w13_t[i], ar.dhn)
+            ops.rmsnorm_bwd(ar.dhn, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
+            ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)
+            g1, g2 = m.gate_views(i)
+            dg1, dg2 = grads.gate_grad_views(i)
+            ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1, dg2,
+                         ar.attn_ws, n_seq, S, H, Dh, A, F)
+            ops.rope_qk(ar.dqkv, self.cos, self.sin, n_seq, S, H, Dh, inverse=True)
+            ops.gemm_nt(ar.dqkv, pk.wqkv_t[i], ar.dxn, tail=g_adapter[i], m_split=R)
+            ops.rmsnorm_bwd(ar.dxn, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, resid=ar.dh, rows=R)
+            cur, nxt = nxt, cur
+        for k, t in enumerate(self.tasks):
+            dh0 = cur[k * B * S:(k + 1) * B * S]
+            if t == "qav":
+                ops.splice_bwd(dh0, ar.d_tok, B, S, F, index=sv["qidx"], mode=1)
+            else:
+                ops.splice_bwd(dh0, ar.d_tok, B, S, F, vstart=vs[t], mode=0)
+        ops.visual_proj_bwd(ar.d_tok, ar.d_qav if has_qav else None, sv["video"],
+                            grads.grad_view("visual_proj.weight"), grads.grad_view("temporal_emb.weight"))
+        self.saved = None
+
+
+class FlatParams:
+    """All trainables of the model as views of ONE flat fp32 buffer (and one flat grad buffer).
+
+    Layout: adapter_query | visual_proj | temporal_emb | gates (L_all, 2, H). Parameter objects keep
+    their reference names/shapes (llama_vqa.py:71-76 freeze policy), only their storage moves."""
+
+    def __init__(self, model):
+        self.model = model
+        named = dict(model.named_parameters())
+        self.names = ["adapter_query.weight", "visual_proj.weight", "temporal_emb.weight"]
+        n_layers = len(model.layers)
+        H = model.params.n_heads
+        sizes = [named[n].numel() for n in self.names]
+        gate_elems = n_layers * 2 * H
+        total = sum(sizes) + gate_elems
+        dev = named[self.names[0]].device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = {}
+        off = 0
+        for n, sz in zip(self.names, sizes):
+            p = named[n]
+            self.flat[off:off + sz].copy_(p.data.reshape(-1).float())
+            p.data = self.flat[off:off + sz].view(p.shape)
+            self.offsets[n] = (off, sz, tuple(p.shape))
+            off += sz
+        self.gate_off = off
+        self.H = H
+        gates = self.flat[off:off + gate_elems].view(n_layers, 2, H)
+        for li, blk in enumerate(model.layers):
+            for j, g in enumerate((blk.attention.gate1, blk.attention.gate2)):
+                gates[li, j].copy_(g.data.reshape(-1).float())
+                g.data = gates[li, j].view(1, H, 1, 1)
+                self.offsets[f"layers.{li}.attention.gate{j + 1}"] = (off + (li * 2 + j) * H, H, (1, H, 1, 1))
+        self.gates = gates
+        self.gate_grads = self.flat_grad[off:off + gate_elems].view(n_layers, 2, H)
+        # per-parameter segment table for the norm-of-norms (util/misc.py:292)
+        segs = sorted(v[0] for v in self.offsets.values()) + [total]
+        self.seg_off = torch.tensor(segs, dtype=torch.int64, device=dev)
+        self.attach_grads()
+
+    def params(self):
+        named = dict(self.model.named_parameters())
+        return [named[n] for n in self.offsets]
+
+    def grad_view(self, name):
+        off, sz, shape = self.offsets[name]
+        return self.flat_grad[off:off + sz].view(shape)
+
+    def gate_grad_views(self, i):
+        li = self.model.engine_layer_ids()[i]
+        return self.gate_grads[li, 0], self.gate_grads[li, 1]
+
+    def attach_grads(self):
+        """p.grad <- view of the flat gradient buffer for every trainable."""
+        named = dict(self.model.named_parameters())
+        for n in self.offsets:
+            p = named[n]
+            if p.requires_grad:
+                p.grad = self.grad_view(n)
+
+    def grads_attached(self) -> bool:
+        named = dict(self.model.named_parameters())
+        for n, (off, sz, shape) in self.offsets.items():
+            g = named[n].grad
+            if g is None or g.data_ptr() != self.flat_grad.data_ptr() + off * 4:
+                return False
+        return True
+
+    def zero_grad(self):
+        self.flat_grad.zero_()

@@ -1,0 +1,178 @@
+/*
+ * fvqa.h — C ABI of libfvqa_hip.so: the MI355X (gfx950) kernels behind the Flipped-VQA
+ * training hot path.
+ *
+ * The reference (inesriahi/Flipped-VQA) is pure Python/PyTorch: its hot path has no FFI of
+ * its own — every entry below replaces an *implicit* torch op group of
+ * llama/model.py:31-365, engine.py:10-56 and util/misc.py:253-294 (file:line cited per
+ * entry, relative to the reference root). The Python host (flipped-vqa_amd/fvqa/_lib.py)
+ * binds them with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator);
+ *     the library never allocates, frees, synchronises or throws;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - `dtype` selects the storage type of activations / frozen weights:
+ *       FVQA_F32  — exact-fp32 validation build of every kernel (fp32-in MFMA),
+ *       FVQA_BF16 — production build (bf16 storage, fp32 accumulate);
+ *     trainable parameters, their gradients, softmax statistics and losses are always fp32;
+ *   - matrices are row-major; `rows` = sequences*seq_len flattened (n*S + s);
+ *   - return value: 0 (FVQA_OK) or a negative FVQA_E* code / -(1000+hipError_t).
+ */
+#ifndef FVQA_H
+#define FVQA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVQA_F32 0
+#define FVQA_BF16 1
+
+#define FVQA_OK 0
+#define FVQA_EINVAL (-1) /* null pointer / bad enum            */
+#define FVQA_ESHAPE (-2) /* dimension not supported by kernels */
+#define FVQA_EALIGN (-3) /* pointer or leading dim misaligned  */
+
+/* GEMM epilogue selector */
+#define FVQA_EPI_NONE 0
+#define FVQA_EPI_RESIDUAL 1 /* C = acc + R                                  */
+
+int fvqa_version(void);      /* ABI version, bumped on any signature change */
+const char* fvqa_arch(void); /* "gfx950"                                     */
+
+/* ---- dense projections: F.linear with frozen weights ---------------------------------
+ * C[M,N] = A[M,K] · B[N,K]^T (+ R[M,N]).  Replaces torch F.linear at llama/model.py:89
+ * (wq/wk/wv), :99-100 (adapter k/v), :127-128 (wo), :142 (w1,w3,w2), :348 (output) and the
+ * autograd dX = dY·W of each (W frozen ⇒ no dW GEMM; the host keeps a transposed copy of
+ * every frozen weight so dX is the same NT form).  A and B have `dtype`; C has `out_dtype`
+ * (FVQA_F32 for LM-head logits). Rows m >= m_split (if tail != NULL) are written as fp32 to
+ * tail[(m - m_split)*N + n] instead of C (adapter-query gradient rows).
+ * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows. */
+int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail,
+                 int M, int N, int K, int lda, int ldb, int ldc, int m_split,
+                 int dtype, int out_dtype, int epilogue, int variant, void* stream);
+
+/* ---- RMSNorm (llama/model.py:37-42; used :185,186,347) -------------------------------- */
+int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int dim,
+                     float eps, int dtype, void* stream);
+/* dx = (resid ? resid : 0) + rmsnorm_bwd(g; x, w, rstd)   (weight frozen ⇒ no dw) */
+int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, const float* rstd,
+                     const void* resid, void* dx, int rows, int dim, int dtype, void* stream);
+
+/* ---- RoPE on the q and k column blocks of a fused qkv buffer (llama/model.py:61-67,96).
+ * qkv is (rows, 3*dim) with q at cols [0,dim), k at [dim,2dim). cos/sin are (S, head_dim/2)
+ * fp32 tables (llama/model.py:45-50). inverse != 0 applies the conjugate rotation (backward).
+ * In place. */
+int fvqa_rope_qk(void* qkv, const float* cos_t, const float* sin_t, int n_seq, int seq_len,
+                 int n_heads, int head_dim, int inverse, int dtype, void* stream);
+
+/* ---- SwiGLU (llama/model.py:142). ab is (rows, 2*hidden): a = cols [0,hidden), b = rest. */
+int fvqa_swiglu_fwd(const void* ab, void* z, int rows, int hidden, int dtype, void* stream);
+/* dab (rows, 2*hidden) <- d/d(a,b) of silu(a)*b given dz (rows, hidden) */
+int fvqa_swiglu_bwd(const void* dz, const void* ab, void* dab, int rows, int hidden, int dtype,
+                    void* stream);
+
+/* ---- adapter-gated prefix attention + causal attention (llama/model.py:98-126) --------
+ * qkv: (n_seq*S + A, 3*dim) — sequence rows then the A adapter rows (whose k and v column
+ * blocks are adapter·Wk^T, adapter·Wv^T, no RoPE). o: (n_seq*S, dim).
+ * gate1, gate2: (H) fp32. vstart: (n_seq) int32, -1 ⇒ no gate2 bias for that sequence
+ * (the QAV stream, llama/model.py:121-122). lse_a/lse_t: (n_seq, H, S) fp32 log-sum-exp of
+ * the adapter softmax and of the causal softmax, saved for the backward. */
+int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1,
+                  const float* gate2, const int32_t* vstart, int n_seq, int seq_len, int n_heads,
+                  int head_dim, int adapter_len, int max_feats, int dtype, void* stream);
+/* workspace bytes fvqa_attn_bwd needs (fp32 partials for the batch-summed adapter k/v
+ * gradients and the per-head gate sums) */
+size_t fvqa_attn_bwd_workspace(int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len);
+/* dqkv: (n_seq*S + A, 3*dim): dq,dk,dv for sequence rows (RoPE NOT yet inverted); adapter rows
+ * get [0, dK_a, dV_a] summed over sequences. dgate1/dgate2 (H) fp32 are ACCUMULATED (+=). */
+int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, const float* lse_a,
+                  const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
+                  void* dqkv, float* dgate1, float* dgate2, void* workspace, size_t workspace_bytes,
+                  int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
+                  int dtype, void* stream);
+
+/* ---- visual projection + temporal embedding (llama/model.py:322,324) ------------------
+ * vf_raw[b,f,:] = video[b,f,:]·W^T (fp32, kept for the QAV head); vf_tok = storage-dtype
+ * cast of vf_raw + temporal[f,:]. video (BF, in_dim) fp32, W (dim, in_dim) fp32. */
+int fvqa_visual_proj_fwd(const float* video, const float* W, const float* temporal, float* vf_raw,
+                         void* vf_tok, int n_frames_total, int max_feats, int in_dim, int dim,
+                         int dtype, void* stream);
+/* d_tok (BF,dim) fp32: gradient wrt the spliced frame tokens (fvqa_splice_bwd); d_qav (BF,dim)
+ * fp32 or NULL: extra gradient wrt vf_raw from the QAV head.
+ * dW (dim,in_dim) += (d_tok + d_qav)^T·video ; dtemporal (F,dim) += sum_b d_tok[b]. */
+int fvqa_visual_proj_bwd(const float* d_tok, const float* d_qav, const float* video, float* dW,
+                         float* dtemporal, int n_frames_total, int max_feats, int in_dim, int dim,
+                         void* stream);
+
+/* ---- token embedding gather + frame splice (llama/model.py:286-294,326-336) -----------
+ * h[n,s,:] = emb[ids[n,s]] (zeroed where zero_labels[n,s] >= 0; NULL = never) then
+ * mode 0 (vqa/vaq): rows [vstart, vstart+F) := vf_tok[n]           (slice assign, :327,:332)
+ * mode 1 (qav):     h[n, index[n,f], :] += vf_tok[n,f]              (scatter_add_, :335-336) */
+int fvqa_embed_splice(const int64_t* ids, const void* emb, const void* vf_tok,
+                      const int64_t* zero_labels, const int64_t* index, void* h, int n_seq,
+                      int seq_len, int dim, int max_feats, int vstart, int mode, int dtype,
+                      void* stream);
+/* d_tok[n,f,:] += dh[n, row(n,f), :] (fp32 accumulate); row = vstart+f (mode 0) or index[n,f] */
+int fvqa_splice_bwd(const void* dh, const int64_t* index, float* d_tok, int n_seq, int seq_len,
+                    int dim, int max_feats, int vstart, int mode, int dtype, void* stream);
+
+/* ---- LM-head cross-entropy (llama/model.py:233-234,349-350,355-356) --------------------
+ * logits (n_seq, S, V) fp32; labels (n_seq, S) int64 — row (n,s) for s < S-1 is scored
+ * against labels[n, s+1]; ignore_index rows are skipped; mean over valid rows.
+ * loss_sum[0] += sum of row losses, loss_sum[1] += number of valid rows (fp32, zero it first).
+ * lse, rowloss (n_seq*S) receive each scored row's log-sum-exp and loss (fixed-order sum). */
+int fvqa_ce_fwd(const float* logits, const int64_t* labels, float* lse, float* rowloss,
+                float* loss_sum, int n_seq, int seq_len, int vocab, int64_t ignore_index,
+                void* stream);
+/* dlogits (n_seq,S,V) storage dtype = (softmax - onehot) * gscale[0] / n_valid on valid rows,
+ * 0 elsewhere (including s = S-1). gscale: device fp32 scalar (upstream grad of the loss). */
+int fvqa_ce_bwd(const float* logits, const int64_t* labels, const float* lse, const float* loss_sum,
+                const float* gscale, void* dlogits, int n_seq, int seq_len, int vocab,
+                int64_t ignore_index, int dtype, void* stream);
+
+/* ---- QAV head (llama/model.py:359-361): logits[n,s,f] = xn[n,s,:]·vf_raw[n,f,:]/tau for
+ * s < S-1, CE(ignore_index=-1) against labels[n,s+1]. xn has storage dtype.
+ * probs (n_seq,S,F) fp32 scratch keeps the softmax for the backward. */
+int fvqa_qav_head_fwd(const void* xn, const float* vf_raw, const int64_t* labels, float* probs,
+                      float* rowloss, float* loss_sum, int n_seq, int seq_len, int dim,
+                      int max_feats, float tau, int dtype, void* stream);
+/* dxn (storage dtype, fully written) and d_raw (n_seq,F,dim) fp32 (+=) */
+int fvqa_qav_head_bwd(const void* xn, const float* vf_raw, const int64_t* labels, const float* probs,
+                      const float* loss_sum, const float* gscale, void* dxn, float* d_raw, int n_seq,
+                      int seq_len, int dim, int max_feats, float tau, int dtype, void* stream);
+
+/* ---- loss-scaler + grad-norm + AdamW (util/misc.py:259-273,282-294; train.py:120-121) --
+ * One flat fp32 buffer holds every trainable gradient; seg_off (n_seg+1) int64 marks the
+ * per-parameter segments. scale, found_inf, step, growth_tracker are DEVICE fp32 scalars, so
+ * the optimizer step needs no device->host read.
+ * fvqa_grad_unscale_norm: g *= 1/scale[0] in place; seg_sq[i] = sum g^2 over segment i;
+ * total_norm[0] = sqrt(sum_i seg_sq[i]) (the norm of per-parameter norms, util/misc.py:292);
+ * found_inf[0] = 1 if any gradient is non-finite else 0 (GradScaler.unscale_). */
+size_t fvqa_grad_norm_workspace(int n_seg);
+int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n_seg, const float* scale,
+                           float* seg_sq, float* found_inf, float* total_norm, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* AdamW (decoupled weight decay, bias correction with t = step[0]+1), skipped entirely when
+ * found_inf[0] != 0 (GradScaler.step semantics). found_inf may be NULL. */
+int fvqa_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    const float* step, const float* found_inf, void* stream);
+/* after the AdamW launches of one optimizer step: step[0] += 1 unless found_inf; dynamic loss
+ * scale update of torch GradScaler (x backoff on overflow, x growth after growth_interval clean
+ * steps). step or scale may be NULL. */
+int fvqa_scaler_update(float* step, float* scale, float* growth_tracker, const float* found_inf,
+                       float growth_factor, float backoff_factor, int growth_interval, void* stream);
+
+/* ---- small utilities -------------------------------------------------------------------
+ * dst rows [row0, row0+n_rows) of a (.., dim) storage-dtype matrix <- fp32 src (n_rows, dim)
+ * (adapter_query rows appended under the normed activations, llama/model.py:339) */
+int fvqa_cast_rows(const float* src, void* dst, int n_rows, int dim, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVQA_H */

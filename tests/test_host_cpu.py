@@ -1,0 +1,181 @@
+"""Host-side logic and the C-ABI surface, no GPU needed."""
+import math
+import os
+import re
+import types
+
+import pytest
+import torch
+
+from fvqa import _lib, synth
+from fvqa.optim import param_groups_weight_decay
+from fvqa.parallel import shard_indices
+from util import lr_sched
+import llama
+import llama_vqa
+import util.misc as misc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    """include/fvqa.h <-> ctypes table <-> the built .so agree symbol for symbol."""
+    text = open(os.path.join(ROOT, "include", "fvqa.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(fvqa_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                                   # binds all of them or raises
+    assert lib.fvqa_version() == _lib.ABI_VERSION
+    assert lib.fvqa_arch() == b"gfx950"
+    # argument validation happens before any launch: callable without a GPU
+    assert lib.fvqa_gemm_nt(None, None, None, None, None, 1, 1, 64, 64, 64, 1, 1, 1, 1, 0, 0, None) == -1
+    assert lib.fvqa_attn_bwd_workspace(2, 128, 32, 128, 10) > 0
+    assert lib.fvqa_attn_bwd_workspace(2, 128, 32, 64, 10) == 0      # head_dim != 128 unsupported
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setenv("FVQA_LIB", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    with pytest.raises(_lib.FvqaLibraryError):
+        _lib.load()
+
+
+def _tiny_model():
+    cfg = synth.preset("tiny", vaq=True, qav=True)
+    args = types.SimpleNamespace(max_feats=10, bias=3.5, tau=100.0, llama_model_path="/nonexistent/", vaq=True,
+                                 qav=True, synthetic=True, vocab_size=cfg.vocab_size, audio=False)
+    ma = llama.ModelArgs(max_seq_len=cfg.max_seq_len, adapter_len=10, adapter_layer=2, **cfg.params_json())
+    ma.vocab_size = cfg.vocab_size
+    return cfg, llama.Transformer(ma, args)
+
+
+def test_model_has_reference_state_dict_and_no_cpu_path():
+    cfg, model = _tiny_model()
+    want = {n: s for n, s, _ in synth.state_spec(cfg)}
+    have = {n: tuple(p.shape) for n, p in model.named_parameters()}
+    assert have == want
+    assert llama.model.swiglu_hidden(4096, 256) == 11008 and llama.model.swiglu_hidden(5120, 256) == 13824
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(synth.make_batch(cfg))
+    with pytest.raises(AssertionError):                     # like the reference: tokenizer file required
+        llama.Tokenizer("/nonexistent/tokenizer.model", args=types.SimpleNamespace())
+
+
+def test_freeze_policy_and_param_groups():
+    cfg, model = _tiny_model()
+    for n, p in model.named_parameters():
+        p.requires_grad = synth.is_trainable(n)
+    no_decay, decay = param_groups_weight_decay(model, 0.14)
+    names = {id(p): n for n, p in model.named_parameters()}
+    got = sorted(names[id(p)] for p in decay["params"])
+    assert no_decay["params"] == [] and no_decay["weight_decay"] == 0.0 and decay["weight_decay"] == 0.14
+    assert got == sorted(n for n in names.values() if synth.is_trainable(n))
+    n7b = sum(math.prod(s) for n, s, _ in synth.state_spec(synth.preset("7b")) if synth.is_trainable(n))
+    assert n7b == 4_499_456                                # 18.0 MB fp32
+
+
+def test_lr_schedule():
+    a = types.SimpleNamespace(lr=0.1, min_lr=0.01, warmup_epochs=2, epochs=10)
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}])
+    assert lr_sched.adjust_learning_rate(opt, 1.0, a) == pytest.approx(0.05)
+    assert opt.param_groups[1]["lr"] == pytest.approx(0.025)
+    assert lr_sched.adjust_learning_rate(opt, 2.0, a) == pytest.approx(0.1)
+    assert lr_sched.adjust_learning_rate(opt, 6.0, a) == pytest.approx(0.01 + 0.09 * 0.5)
+    assert lr_sched.adjust_learning_rate(opt, 10.0, a) == pytest.approx(0.01)
+
+
+def test_synthetic_batch_schema():
+    cfg = synth.preset("7b", vaq=True, qav=True, batch_size=4)
+    b = synth.make_batch(cfg, seed=3)
+    B, S, F = 4, 128, 10
+    assert b["video"].shape == (B, F, 768) and b["video"].dtype == torch.float32
+    for t in ("vqa", "vaq", "qav"):
+        assert b["text_id"][t].shape == (B, 1, S) and b["text_id"][t].dtype == torch.int64
+        assert b["label"][t].shape == (B, 1, S)
+        assert 0 <= int(b["text_id"][t].min()) and int(b["text_id"][t].max()) < 32000
+    vs = b["video_start"]["vqa"][0]
+    assert (b["text_id"]["vqa"][:, 0, vs:vs + F] == 0).all()
+    assert (b["label"]["vqa"] != 0).sum(-1).min() >= 1 and (b["label"]["vqa"][..., : vs + F] == 0).all()
+    q = b["label"]["qav"][:, 0]
+    idx = b["video_index"]["qav"]
+    assert ((q >= 0).sum(-1) == F).all()
+    assert torch.equal(q.gather(1, idx), torch.arange(F).repeat(B, 1))
+    b2 = synth.make_batch(cfg, seed=3)
+    assert torch.equal(b["video"], b2["video"]) and torch.equal(b["text_id"]["vaq"], b2["text_id"]["vaq"])
+
+
+def test_closed_form_generator_is_stable():
+    t = synth.hashed_uniform("layers.0.attention.wq.weight", (4, 8), 0.5)
+    assert t.shape == (4, 8) and float(t.abs().max()) <= 0.5
+    assert torch.equal(t, synth.hashed_uniform("layers.0.attention.wq.weight", (4, 8), 0.5))
+    big = synth.hashed_uniform("x", (1 << 16,), 1.0)
+    assert abs(float(big.mean())) < 0.02 and abs(float(big.var()) - 1 / 3) < 0.02
+
+
+def test_merge_shards_follows_meta_split_dims():
+    D, Hf, V = 8, 12, 10
+    full = {"tok_embeddings.weight": torch.randn(V, D), "norm.weight": torch.randn(D), "output.weight": torch.randn(V, D),
+            "layers.0.attention.wq.weight": torch.randn(D, D), "layers.0.attention.wo.weight": torch.randn(D, D),
+            "layers.0.feed_forward.w1.weight": torch.randn(Hf, D), "layers.0.feed_forward.w2.weight": torch.randn(D, Hf),
+            "layers.0.attention_norm.weight": torch.randn(D), "rope.freqs": torch.randn(4)}
+    col = ("wq.weight", "w1.weight", "output.weight")
+    row = ("wo.weight", "w2.weight", "tok_embeddings.weight")
+    shards = [{}, {}]
+    for n, t in full.items():
+        for r in range(2):
+            if n.endswith(col):
+                shards[r][n] = t.chunk(2, 0)[r]
+            elif n.endswith(row):
+                shards[r][n] = t.chunk(2, 1)[r]
+            else:
+                shards[r][n] = t
+    merged = llama_vqa.merge_shards(shards, 1)
+    for n, t in full.items():
+        if n == "rope.freqs":
+            assert n not in merged
+        else:
+            assert torch.equal(merged[n], t), n
+    assert llama_vqa.merge_shards([full], 1) is full
+
+
+def test_shard_indices_match_distributed_sampler():
+    from torch.utils.data import DistributedSampler
+    ds = list(range(23))
+    for epoch in (0, 3):
+        for rank in range(4):
+            s = DistributedSampler(ds, num_replicas=4, rank=rank, shuffle=True, seed=0)
+            s.set_epoch(epoch)
+            assert list(s) == shard_indices(23, rank, 4, epoch=epoch, shuffle=True, seed=0)
+
+
+def test_metric_logger_and_scaler_state():
+    log = misc.MetricLogger(delimiter="  ")
+    log.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    seen = [x for x in log.log_every([1, 2, 3], 0, "Epoch: [0]")]      # print_freq 0 must not crash
+    assert seen == [1, 2, 3]
+    log.update(loss=2.0, lr=0.1)
+    log.update(loss=4.0)
+    assert log.meters["loss"].global_avg == 3.0 and "lr: 0.100000" in str(log)
+    sc = misc.NativeScalerWithGradNormCount()
+    sd = sc.state_dict()
+    assert sd["scale"] == 65536.0 and set(sd) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    sc.load_state_dict({"scale": 128.0, "_growth_tracker": 5})
+    assert sc.state_dict()["scale"] == 128.0
+    assert misc.NativeScalerWithGradNormCount.state_dict_key == "amp_scaler"
+
+
+def test_train_cli_has_reference_flags():
+    import train
+    p = train.get_args_parser()
+    a = p.parse_args(["--model", "7B", "--max_seq_len", "128", "--batch_size", "8", "--vaq", "--qav", "--bias", "3.5",
+                      "--tau", "100", "--blr", "9e-2", "--weight_decay", "0.14", "--accum_iter", "2", "--dataset", "nextqa"])
+    for k in ("batch_size epochs accum_iter llama_model_path model adapter_layer adapter_len max_seq_len max_feats "
+              "weight_decay lr blr min_lr warmup_epochs dataset output_dir device seed resume start_epoch num_workers "
+              "pin_mem world_size local_rank dist_on_itp dist_url vaq qav bias tau sub is_generation_task debug jobid "
+              "audio audio_only audio_merge").split():
+        assert hasattr(a, k), k
+    assert a.adapter_layer == 32 and a.adapter_len == 10 and a.bias == 3.5 and a.pin_mem is True
+    train.validate_args(a)
+    a.audio_only = True
+    with pytest.raises(AssertionError):
+        train.validate_args(a)

@@ -1,0 +1,369 @@
+"""Per-kernel parity: every C-ABI entry of libfvqa_hip.so against the oracle primitive
+(oracle/ref_cpu.py, fp64 on CPU) on seeded inputs. fp32 build: tolerance 2e-5 of the output's
+max magnitude (GEMM K<=4096: 5e-5); bf16 build: 2e-2 (8-bit mantissa storage). Run with -m gpu."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fvqa import ops  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, f32=2e-5, bf16=2e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def rel(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    x = (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+    return x.to(dtype)            # CPU tensor in storage precision
+
+
+def dev(x):
+    return x.to(DEV).contiguous()
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 256), (138, 256, 512), (1034, 768, 256),
+                                   (77, 200, 128), (1024, 4096, 4096)])
+def test_gemm_nt(dtype, variant, M, N, K):
+    if (M, N, K) == (1024, 4096, 4096) and variant == 1 and dtype == torch.float32:
+        pytest.skip("covered by variant 0")
+    a, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=1 / math.sqrt(K), seed=2)
+    out = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out, variant=variant)
+    ref = a.double() @ b.double().T
+    assert rel(out, ref) < tol(dtype, 5e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_identity_asymmetric(dtype):
+    """A = I (padded) against an asymmetric B catches a transposed C write or a wrong k order."""
+    M = N = K = 128
+    a = torch.eye(M, K, dtype=dtype)
+    b = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 0.5).to(dtype)     # exactly representable
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out)
+    assert torch.equal(out.cpu(), b.float().T.contiguous())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_residual_tail_f32out(dtype):
+    M, N, K, split = 266, 256, 192, 256
+    a, b = rnd(M, K, dtype=dtype, seed=3), rnd(N, K, dtype=dtype, scale=0.1, seed=4)
+    r = rnd(split, N, dtype=dtype, seed=5)
+    out = torch.full((split, N), 7.0, dtype=dtype, device=DEV)
+    tail = torch.ones(M - split, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out, residual=dev(r), tail=tail, m_split=split)
+    ref = a.double() @ b.double().T
+    assert rel(out, ref[:split] + r.double()) < tol(dtype, 5e-5, 1e-2)
+    assert rel(tail, ref[split:] + 1.0) < tol(dtype, 5e-5, 2e-3)      # tail accumulates in fp32
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out32)
+    assert rel(out32, ref) < tol(dtype, 5e-5, 2e-3)
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(64, 48, device=DEV)
+    b = torch.zeros(64, 48, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, b, torch.empty(64, 64, device=DEV))          # K % 32 != 0
+    with pytest.raises(ValueError):
+        ops.gemm_nt(a, torch.zeros(64, 32, device=DEV), torch.empty(64, 64, device=DEV))
+    with pytest.raises(ValueError):
+        ops.gemm_nt(a.cpu(), b.cpu(), torch.empty(64, 64))            # no CPU fallback
+
+
+# ------------------------------------------------------------------------------ row ops
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,dim", [(7, 256), (130, 4096), (33, 5120)])
+def test_rmsnorm(dtype, rows, dim):
+    x, w, g = rnd(rows, dim, dtype=dtype, seed=1), (rnd(dim, dtype=dtype, scale=0.1, seed=2).float() + 1).to(dtype), \
+        rnd(rows, dim, dtype=dtype, seed=3)
+    res = rnd(rows, dim, dtype=dtype, seed=4)
+    y = torch.empty(rows, dim, dtype=dtype, device=DEV)
+    rstd = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.rmsnorm_fwd(dev(x), dev(w), y, rstd, 1e-6)
+    yr, rr = ref_cpu.rmsnorm_fwd(x.double(), w.double(), 1e-6)
+    assert rel(y, yr) < tol(dtype)
+    assert rel(rstd, rr[:, 0]) < 1e-5
+    dx = torch.empty(rows, dim, dtype=dtype, device=DEV)
+    ops.rmsnorm_bwd(dev(g), dev(x), dev(w), rstd, dx, resid=dev(res))
+    dxr = ref_cpu.rmsnorm_bwd(g.double(), x.double(), w.double(), rr) + res.double()
+    assert rel(dx, dxr) < tol(dtype)
+    ops.rmsnorm_bwd(dev(g), dev(x), dev(w), rstd, dx)
+    assert rel(dx, dxr - res.double()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rope(dtype):
+    N, S, H, Dh = 2, 24, 3, 128
+    D = H * Dh
+    qkv = rnd(N * S + 5, 3 * D, dtype=dtype, seed=9)
+    cos, sin = ref_cpu.rope_tables(64, Dh, torch.float32)
+    buf = dev(qkv)
+    ops.rope_qk(buf, dev(cos), dev(sin), N, S, H, Dh)
+    q = qkv[: N * S, :D].double().view(N, S, H, Dh)
+    k = qkv[: N * S, D:2 * D].double().view(N, S, H, Dh)
+    qr = ref_cpu.rope_apply(q, cos[:S].double(), sin[:S].double())
+    kr = ref_cpu.rope_apply(k, cos[:S].double(), sin[:S].double())
+    got = buf.float().cpu()
+    assert rel(got[: N * S, :D], qr.reshape(N * S, D)) < tol(dtype, bf16=1e-2)
+    assert rel(got[: N * S, D:2 * D], kr.reshape(N * S, D)) < tol(dtype, bf16=1e-2)
+    assert torch.equal(got[: N * S, 2 * D:], qkv[: N * S, 2 * D:].float())          # v untouched
+    assert torch.equal(got[N * S:], qkv[N * S:].float())                            # adapter rows untouched
+    if dtype == torch.float32:                                                      # inverse undoes it
+        ops.rope_qk(buf, dev(cos), dev(sin), N, S, H, Dh, inverse=True)
+        assert rel(buf, qkv) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_swiglu(dtype):
+    rows, hidden = 37, 768
+    ab, dz = rnd(rows, 2 * hidden, dtype=dtype, scale=3, seed=1), rnd(rows, hidden, dtype=dtype, seed=2)
+    z = torch.empty(rows, hidden, dtype=dtype, device=DEV)
+    ops.swiglu_fwd(dev(ab), z, rows, hidden)
+    a, b = ab[:, :hidden].double(), ab[:, hidden:].double()
+    assert rel(z, ref_cpu.silu(a) * b) < tol(dtype)
+    dab = torch.empty(rows, 2 * hidden, dtype=dtype, device=DEV)
+    ops.swiglu_bwd(dev(dz), dev(ab), dab, rows, hidden)
+    da, db = ref_cpu.swiglu_bwd(dz.double(), a, b)
+    assert rel(dab[:, :hidden], da) < tol(dtype)
+    assert rel(dab[:, hidden:], db) < tol(dtype)
+
+
+# ------------------------------------------------------------------------------ attention
+def _attn_case(dtype, N, S, H, A, F, vstart, seed=0):
+    Dh, D = 128, H * 128
+    qkv = rnd(N * S + A, 3 * D, dtype=dtype, scale=1.0, seed=seed)
+    g1 = rnd(H, seed=seed + 1).float()
+    g2 = (rnd(H, seed=seed + 2).float() - 3.0)
+    return qkv, g1, g2, torch.tensor(vstart, dtype=torch.int32), Dh, D
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,S,H,vstart", [(2, 32, 2, [5, -1]), (3, 128, 2, [19, 19, -1]), (1, 200, 1, [19]),
+                                          (2, 70, 3, [-1, 8])])
+def test_attention_fwd_bwd(dtype, N, S, H, vstart):
+    A, F = 10, 10
+    qkv, g1, g2, vs, Dh, D = _attn_case(dtype, N, S, H, A, F, vstart, seed=S)
+    d_o = rnd(N * S, D, dtype=dtype, seed=77)
+    q = qkv[: N * S, :D].double().view(N, S, H, Dh)
+    k = qkv[: N * S, D:2 * D].double().view(N, S, H, Dh)
+    v = qkv[: N * S, 2 * D:].double().view(N, S, H, Dh)
+    ak = qkv[N * S:, D:2 * D].double().view(A, H, Dh)
+    av = qkv[N * S:, 2 * D:].double().view(A, H, Dh)
+    o_ref, cache = ref_cpu.attn_fwd(q, k, v, ak, av, g1.double(), g2.double(), vstart, F)
+
+    o = torch.empty(N * S, D, dtype=dtype, device=DEV)
+    lse_a = torch.empty(N * H * S, dtype=torch.float32, device=DEV)
+    lse_t = torch.empty_like(lse_a)
+    qkv_d, g1d, g2d, vsd = dev(qkv), dev(g1), dev(g2), dev(vs)
+    ops.attn_fwd(qkv_d, o, lse_a, lse_t, g1d, g2d, vsd, N, S, H, Dh, A, F)
+    assert rel(o, o_ref.reshape(N * S, D)) < tol(dtype, 3e-5, 1e-2)
+
+    dq, dk, dv, dak, dav, dg1, dg2 = ref_cpu.attn_bwd(d_o.double().view(N, S, H, Dh), q, k, v, ak, av, g1.double(),
+                                                      g2.double(), vstart, F, cache)
+    dqkv = torch.full((N * S + A, 3 * D), float("nan"), dtype=dtype, device=DEV)
+    dg1d = torch.ones(H, dtype=torch.float32, device=DEV)          # kernels accumulate into these
+    dg2d = torch.ones(H, dtype=torch.float32, device=DEV)
+    ws = torch.empty(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
+    # the backward consumes the forward's own (storage-rounded) o
+    ops.attn_bwd(dev(d_o), qkv_d, o, lse_a, lse_t, g1d, g2d, vsd, dqkv, dg1d, dg2d, ws, N, S, H, Dh, A, F)
+    t = tol(dtype, 5e-5, 2e-2)
+    got = dqkv.float().cpu()
+    assert not torch.isnan(got).any()
+    assert rel(got[: N * S, :D], dq.reshape(N * S, D)) < t
+    assert rel(got[: N * S, D:2 * D], dk.reshape(N * S, D)) < t
+    assert rel(got[: N * S, 2 * D:], dv.reshape(N * S, D)) < t
+    assert rel(got[N * S:, D:2 * D], dak.reshape(A, D)) < t
+    assert rel(got[N * S:, 2 * D:], dav.reshape(A, D)) < t
+    assert float(got[N * S:, :D].abs().max()) == 0.0
+    assert rel(dg1d - 1.0, dg1) < max(t, 1e-4)
+    assert rel(dg2d - 1.0, dg2) < max(t, 1e-4)
+
+
+def test_attention_is_deterministic():
+    N, S, H, A, F = 2, 128, 2, 10, 10
+    qkv, g1, g2, vs, Dh, D = _attn_case(torch.float32, N, S, H, A, F, [19, -1], seed=3)
+    outs = []
+    for _ in range(2):
+        o = torch.empty(N * S, D, device=DEV)
+        la = torch.empty(N * H * S, device=DEV)
+        lt = torch.empty_like(la)
+        ops.attn_fwd(dev(qkv), o, la, lt, dev(g1), dev(g2), dev(vs), N, S, H, Dh, A, F)
+        dqkv = torch.empty(N * S + A, 3 * D, device=DEV)
+        dg1, dg2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        ws = torch.empty(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
+        ops.attn_bwd(o.clone(), dev(qkv), o, la, lt, dev(g1), dev(g2), dev(vs), dqkv, dg1, dg2, ws, N, S, H, Dh, A, F)
+        outs.append((o.cpu(), dqkv.cpu(), dg1.cpu(), dg2.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)          # no atomics: bitwise repeatable
+
+
+# ------------------------------------------------------------------------------ heads, splice
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_visual_proj(dtype):
+    B, F, K, D = 3, 10, 768, 512
+    video, W, temp = rnd(B * F, K, seed=1), rnd(D, K, scale=1 / math.sqrt(K), seed=2), rnd(F, D, seed=3)
+    raw = torch.empty(B * F, D, device=DEV)
+    tok = torch.empty(B * F, D, dtype=dtype, device=DEV)
+    ops.visual_proj_fwd(dev(video), dev(W), dev(temp), raw, tok)
+    ref = video.double() @ W.double().T
+    assert rel(raw, ref) < 2e-6
+    assert rel(tok, ref + temp.double().repeat(B, 1)) < tol(dtype, 2e-6, 5e-3)
+    d_tok, d_qav = rnd(B * F, D, seed=4), rnd(B * F, D, seed=5)
+    dW = torch.ones(D, K, device=DEV)
+    dT = torch.ones(F, D, device=DEV)
+    ops.visual_proj_bwd(dev(d_tok), dev(d_qav), dev(video), dW, dT)
+    assert rel(dW - 1, (d_tok + d_qav).double().T @ video.double()) < 2e-6
+    assert rel(dT - 1, d_tok.double().view(B, F, D).sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_splice_and_backward(dtype):
+    B, S, F, D, V = 3, 40, 10, 256, 300
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V, (B, S), generator=g)
+    emb, vf = rnd(V, D, dtype=dtype, seed=1), rnd(B * F, D, dtype=dtype, seed=2)
+    h = torch.empty(B * S, D, dtype=dtype, device=DEV)
+    ops.embed_splice(dev(ids), dev(emb), dev(vf), h, B, S, F, vstart=7, mode=0)
+    ref = emb[ids].clone()
+    ref[:, 7:17] = vf.view(B, F, D)
+    assert torch.equal(h.cpu().view(B, S, D), ref)
+    # qav: zero label-marked rows then scatter-add at per-sample indices
+    lab = torch.full((B, S), -1, dtype=torch.int64)
+    idx = torch.stack([torch.arange(p, p + F) for p in (5, 20, 29)])
+    for b in range(B):
+        lab[b, idx[b]] = torch.arange(F)
+    ops.embed_splice(dev(ids), dev(emb), dev(vf), h, B, S, F, zero_labels=dev(lab), index=dev(idx), mode=1)
+    ref = emb[ids].clone() * (~(lab >= 0))[..., None]
+    ref.scatter_add_(1, idx[..., None].repeat(1, 1, D), vf.view(B, F, D))
+    assert torch.equal(h.cpu().view(B, S, D), ref)
+    dh = rnd(B * S, D, dtype=dtype, seed=5)
+    d_tok = torch.ones(B * F, D, device=DEV)
+    ops.splice_bwd(dev(dh), d_tok, B, S, F, vstart=7, mode=0)
+    ops.splice_bwd(dev(dh), d_tok, B, S, F, index=dev(idx), mode=1)
+    want = 1 + dh.view(B, S, D)[:, 7:17].float() + dh.view(B, S, D).float().gather(1, idx[..., None].repeat(1, 1, D))
+    assert rel(d_tok.view(B, F, D), want) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cross_entropy(dtype):
+    B, S, V = 3, 17, 1000
+    logits = rnd(B * S, V, scale=6, seed=1)
+    g = torch.Generator().manual_seed(1)
+    labels = torch.randint(1, V, (B, S), generator=g)
+    labels[torch.rand(B, S, generator=g) < 0.6] = 0
+    labels[0, 3] = 5
+    lse = torch.empty(B * S, device=DEV)
+    rowloss = torch.empty(B * S, device=DEV)
+    loss_sum = torch.zeros(2, device=DEV)
+    ops.ce_fwd(dev(logits), dev(labels), lse, rowloss, loss_sum, B, S, V, 0)
+    lg = logits.double().view(B, S, V)[:, :-1].reshape(-1, V)
+    lab = labels[:, 1:].flatten()
+    loss, dl = ref_cpu.ce_mean(lg, lab, 0)
+    got = (loss_sum[0] / loss_sum[1]).item()
+    assert abs(got - loss.item()) / loss.item() < 2e-6
+    assert int(loss_sum[1].item()) == int((lab != 0).sum())
+    gs = torch.tensor([2.5], device=DEV)
+    dlog = torch.full((B * S, V), float("nan"), dtype=dtype, device=DEV)
+    ops.ce_bwd(dev(logits), dev(labels), lse, loss_sum, gs, dlog, B, S, V, 0)
+    want = torch.zeros(B, S, V, dtype=torch.float64)
+    want[:, :-1] = dl.view(B, S - 1, V) * 2.5
+    assert rel(dlog, want.view(B * S, V)) < tol(dtype, 1e-5, 1e-2)
+
+
+def test_cross_entropy_all_ignored_is_nan():
+    B, S, V = 1, 8, 64
+    loss_sum = torch.zeros(2, device=DEV)
+    ops.ce_fwd(torch.zeros(B * S, V, device=DEV), torch.zeros(B, S, dtype=torch.int64, device=DEV),
+               torch.empty(B * S, device=DEV), torch.empty(B * S, device=DEV), loss_sum, B, S, V, 0)
+    assert math.isnan((loss_sum[0] / loss_sum[1]).item())          # as torch CE; engine.py:33-35 then aborts
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_qav_head(dtype):
+    B, S, D, F, tau = 3, 30, 512, 10, 100.0
+    xn = rnd(B * S, D, dtype=dtype, seed=1)
+    vf = rnd(B * F, D, scale=3, seed=2)
+    labels = torch.full((B, S), -1, dtype=torch.int64)
+    for b, p in enumerate((4, 11, 19)):
+        labels[b, p:p + F] = torch.arange(F)
+    probs = torch.empty(B * S * F, device=DEV)
+    rowloss = torch.empty(B * S, device=DEV)
+    loss_sum = torch.zeros(2, device=DEV)
+    ops.qav_head_fwd(dev(xn), dev(vf), dev(labels), probs, rowloss, loss_sum, B, S, D, F, tau)
+    x64 = xn.double().view(B, S, D)
+    ql = torch.einsum("nsd,nfd->nsf", x64[:, :-1], vf.double().view(B, F, D)) / tau
+    loss, dl = ref_cpu.ce_mean(ql.reshape(-1, F), labels[:, 1:].flatten(), -1)
+    assert abs((loss_sum[0] / loss_sum[1]).item() - loss.item()) / loss.item() < 1e-5
+    gs = torch.tensor([0.5], device=DEV)
+    dxn = torch.full((B * S, D), float("nan"), dtype=dtype, device=DEV)
+    d_raw = torch.ones(B * F, D, device=DEV)
+    ops.qav_head_bwd(dev(xn), dev(vf), dev(labels), probs, loss_sum, gs, dxn, d_raw, B, S, D, F, tau)
+    dl = dl.view(B, S - 1, F) * (0.5 / tau)
+    want_x = torch.zeros(B, S, D, dtype=torch.float64)
+    want_x[:, :-1] = torch.einsum("nsf,nfd->nsd", dl, vf.double().view(B, F, D))
+    want_v = torch.einsum("nsf,nsd->nfd", dl, x64[:, :-1])
+    assert rel(dxn, want_x.view(B * S, D)) < tol(dtype, 1e-5, 1e-2)
+    assert rel(d_raw - 1, want_v.reshape(B * F, D)) < 1e-5
+
+
+# ------------------------------------------------------------------------------ optimizer
+def test_grad_norm_and_adamw_match_torch():
+    torch.manual_seed(0)
+    sizes = [5000, 64, 64, 70000, 32]
+    off = [0]
+    for s in sizes:
+        off.append(off[-1] + s)
+    n = off[-1]
+    p0, g0 = torch.randn(n), torch.randn(n) * 3
+    scale = 1024.0
+    flat, grad = dev(p0.clone()), dev(g0 * scale)
+    seg = torch.tensor(off, dtype=torch.int64, device=DEV)
+    seg_sq = torch.empty(len(sizes), device=DEV)
+    found, norm = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    ws = torch.empty(ops.grad_norm_workspace(len(sizes)), dtype=torch.uint8, device=DEV)
+    sc = torch.tensor([scale], device=DEV)
+    ops.grad_unscale_norm(grad, seg, sc, seg_sq, found, norm, ws)
+    per = torch.stack([g0[a:b].double().norm() for a, b in zip(off[:-1], off[1:])])
+    assert abs(norm.item() - per.norm().item()) / per.norm().item() < 1e-6
+    assert found.item() == 0.0 and rel(grad, g0) < 1e-6
+    # three AdamW steps against torch.optim.AdamW
+    ref_p = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([ref_p], lr=0.05, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.14)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, device=DEV)
+    tracker = torch.zeros(1, device=DEV)
+    for it in range(3):
+        ref_p.grad = (g0 * (it + 1)).double()
+        opt.step()
+        ops.adamw_step(flat, dev(g0 * (it + 1)), m, v, 0.05, 0.9, 0.95, 1e-8, 0.14, step, found)
+        ops.scaler_update(step, sc, tracker, found, 2.0, 0.5, 2)
+    assert step.item() == 3.0
+    assert rel(flat, ref_p.detach()) < 2e-6
+    assert sc.item() == scale * 2.0                      # grew once after 2 clean steps
+    # overflow: update skipped, scale halves, step does not advance
+    grad2 = dev(g0.clone())
+    grad2[17] = float("inf")
+    ops.grad_unscale_norm(grad2, seg, sc, seg_sq, found, norm, ws)
+    assert found.item() == 1.0
+    before = flat.clone()
+    ops.adamw_step(flat, grad2, m, v, 0.05, 0.9, 0.95, 1e-8, 0.14, step, found)
+    ops.scaler_update(step, sc, tracker, found, 2.0, 0.5, 2)
+    assert torch.equal(flat, before) and step.item() == 3.0 and sc.item() == scale

@@ -56,8 +56,8 @@ def run_step(model, batch, loss_weights=(1.0, 1.0, 1.0)):
     B = batch["video"].shape[0]
     S = batch["text_id"]["vqa"].shape[-1]
     ar = eng.arena(eng.n_streams * B, S)
-    losses = {"vqa": float(vqa), "vaq": float(vaq) if model.args.vaq else 0.0,
-              "qav": float(qav) if model.args.qav else 0.0}
+    losses = {"vqa": float(vqa.detach()), "vaq": float(vaq.detach()) if model.args.vaq else 0.0,
+              "qav": float(qav.detach()) if model.args.qav else 0.0}
     grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
     logits = {}
     for k, t in enumerate(eng.tasks):

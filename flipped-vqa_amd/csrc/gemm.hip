@@ -204,10 +204,16 @@ int launch_128(const void* A, const void* B, void* C, const void* R, float* tail
 
 }  // namespace
 
-// variant: 0 = default (LDS-DMA staging), 1 = register-staged (same LDS image; A/B cross-check)
+int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, float* tail, void* ws,
+                          size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
+                          int out_dtype, int epilogue, int force_splits, hipStream_t st);
+
+// variant: 0 = auto (256x256 ring kernel with automatic split-K when the problem is large enough,
+// else the 128x128 kernel); 1 = 128x128 register-staged; 2 = 128x128 LDS-DMA; 3 = 256x256, auto
+// splits; 16+s = 256x256 with exactly s K-splits (tests / tuning).
 extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail, int M, int N,
                             int K, int lda, int ldb, int ldc, int m_split, int dtype, int out_dtype, int epilogue,
-                            int variant, void* stream) {
+                            int variant, void* workspace, size_t workspace_bytes, void* stream) {
   if (!A || !B || !C) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype) || !fvqa_dtype_ok(out_dtype)) return FVQA_EINVAL;
   if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL) return FVQA_EINVAL;
@@ -221,6 +227,10 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
     return FVQA_EALIGN;
   if (lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const bool big = variant == 3 || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
+  if (big)
+    return fvqa_gemm_nt_256_impl(A, B, C, R, tail, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, m_split, dtype,
+                                 out_dtype, epilogue, variant >= 16 ? variant - 16 : 0, st);
   const bool glds = variant != 1;
   if (dtype == FVQA_BF16) {
     if (out_dtype == FVQA_F32)

@@ -1,0 +1,288 @@
+// 256x256-tile projection GEMM for gfx950 with a 4-deep LDS-DMA ring and split-K.
+//
+// Why a second tile size: a 128x128 tile has to pull (128+128) x 128 B per K-step for 512 MFMA
+// cycles per SIMD, i.e. 64 B/clk per CU — the CU's whole L2->LDS fill rate — so that family tops
+// out near 700 TF/s on MI355X whatever its schedule. A 256x256 tile needs 32 B/clk.
+//
+// Structure (512 threads = 8 waves as 2(M) x 4(N), 128x64 outputs per wave = 8x4 MFMA 16x16 tiles,
+// 128 accumulator registers):
+//   * K is consumed in stages of 64 bytes per row (32 bf16 / 16 fp32) = one MFMA k-step;
+//   * a stage is 16 KiB of A + 16 KiB of B, filled by 4 global_load_lds_dwordx4 per wave;
+//   * the LDS ring holds 4 stages (128 KiB): stage t+3 is issued while stage t is computed, so a
+//     load has three compute periods (~1.5k cycles) to land — enough to stream weights from HBM
+//     with ONE workgroup per CU;
+//   * one raw s_barrier per stage, guarded by a COUNTED s_waitcnt vmcnt (never 0 in steady state):
+//     the barrier both publishes stage t (every wave's DMA for it has landed) and retires the
+//     reads of stage t-1, whose slot the next DMA overwrites;
+//   * LDS image is lane-linear (DMA constraint); the 64-byte rows are XOR-swizzled on the SOURCE
+//     address and on the ds_read_b128 fragment read with g(row) = (-(row>>2)) & 3, which makes
+//     every 16-lane read group hit 16 distinct 16-byte bank slots.
+// Grid filling: M is only 1024..3072 rows here, so outputs with few tiles (N = 4096: 64 tiles on
+// 256 CUs) are split along K over blockIdx ranges; partial sums go to an fp32 workspace
+// [split][M][N] and `splitk_fixup` adds them (+ residual, fp32 tail rows) in one pass.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 256, TN = 256;
+constexpr int SROW = 64;                 // bytes of K per row per stage
+constexpr int STAGE_OP = TM * SROW;      // 16 KiB per operand per stage
+constexpr int STAGE = 2 * STAGE_OP;      // 32 KiB
+constexpr int NSTAGE = 4;
+constexpr int LDS256 = NSTAGE * STAGE;   // 128 KiB
+
+template <typename T> struct Mma256;
+template <> struct Mma256<bf16_t> {
+  static constexpr int KE = 32;          // elements per stage
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                  __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma256<float> {
+  static constexpr int KE = 16;
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+// EPI: 0 none, 1 residual. SPLIT: write fp32 partials to `ws` instead of C.
+template <typename T, typename TO, int EPI, bool SPLIT>
+__global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, const T* __restrict__ B,
+                                                   TO* __restrict__ C, const T* __restrict__ R,
+                                                   float* __restrict__ tail, float* __restrict__ ws, int M, int N,
+                                                   int K, int lda, int ldb, int ldc, int m_split, int tiles_m,
+                                                   int splits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KE = Mma256<T>::KE;
+  constexpr int CH = 16 / (int)sizeof(T);
+
+  // work id -> (m tile fastest, then K split, then n tile): neighbours share the weight panel
+  const int wid = xcd_remap256(blockIdx.x, gridDim.x);
+  const int tmi = wid % tiles_m;
+  const int sp = (wid / tiles_m) % splits;
+  const int tni = wid / (tiles_m * splits);
+  const int m0 = tmi * TM, n0 = tni * TN;
+  const int nk_all = K / KE;
+  const int kbeg = (int)(((long long)nk_all * sp) / splits);
+  const int kend = (int)(((long long)nk_all * (sp + 1)) / splits);
+  const int nk = kend - kbeg;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+
+  // ---- DMA geometry: wave w fills pieces 2w, 2w+1 of A and of B (piece = 16 rows x 64 B = 1 KiB)
+  const T* srcA[2];
+  const T* srcB[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int piece = w * 2 + t;
+    const int row = piece * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
+    int ga = m0 + row; ga = ga < M ? ga : M - 1;
+    int gb = n0 + row; gb = gb < N ? gb : N - 1;
+    srcA[t] = A + (size_t)ga * lda + (size_t)kbeg * KE + c * CH;
+    srcB[t] = B + (size_t)gb * ldb + (size_t)kbeg * KE + c * CH;
+  }
+  auto issue = [&](int st) {                 // stage index st (relative to kbeg) -> ring slot st & 3
+    char* dA = smem + (st & (NSTAGE - 1)) * STAGE;
+    char* dB = dA + STAGE_OP;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int piece = w * 2 + t;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[t] + (size_t)st * KE),
+                                       (__attribute__((address_space(3))) void*)(dA + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[t] + (size_t)st * KE),
+                                       (__attribute__((address_space(3))) void*)(dB + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read: row (lane&15) of each 16-row block, 16-byte chunk (lane>>4), swizzled
+  const int frow = lane & 15;
+  const int fch = ((lane >> 4) ^ ((-(frow >> 2)) & 3)) << 4;
+  const int offA = (wr * 128 + frow) * SROW + fch;
+  const int offB = STAGE_OP + (wc * 64 + frow) * SROW + fch;
+
+  // prologue: three stages in flight
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+
+  // LDS fragment reads are inline asm on purpose: hipcc's waitcnt pass makes every compiler-visible
+  // LDS load wait for ALL in-flight LDS-DMA (s_waitcnt vmcnt(0)), which would drain the ring each
+  // stage. The reads return in issue order, so counted lgkmcnt waits release the MFMAs row by row;
+  // each wait statement names the registers it guards ("+v") so no consumer is scheduled above it.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#define FVQA_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define FVQA_ROW(i, n)                                                                 \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
+  Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
+  Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < nk; ++t) {
+    // my own DMA for stage t has landed once at most (stages newer than t) * 4 loads are pending
+    const int newer = min(nk - t - 1, 2);
+    if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // stage t complete for all waves; slot (t-1)&3 is free
+    asm volatile("" ::: "memory");
+    if (t + 3 < nk) issue(t + 3);
+    const unsigned sb = lds0 + (unsigned)((t & (NSTAGE - 1)) * STAGE);
+    const unsigned pa = sb + (unsigned)offA, pb = sb + (unsigned)offB;
+    u32x4 a[8], b[4];
+    FVQA_DSR(b[0], pb, 0);    FVQA_DSR(b[1], pb, 1024); FVQA_DSR(b[2], pb, 2048); FVQA_DSR(b[3], pb, 3072);
+    FVQA_DSR(a[0], pa, 0);    FVQA_DSR(a[1], pa, 1024); FVQA_DSR(a[2], pa, 2048); FVQA_DSR(a[3], pa, 3072);
+    FVQA_DSR(a[4], pa, 4096); FVQA_DSR(a[5], pa, 5120); FVQA_DSR(a[6], pa, 6144); FVQA_DSR(a[7], pa, 7168);
+    asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    FVQA_ROW(0, 7) FVQA_ROW(1, 6) FVQA_ROW(2, 5) FVQA_ROW(3, 4)
+    FVQA_ROW(4, 3) FVQA_ROW(5, 2) FVQA_ROW(6, 1) FVQA_ROW(7, 0)
+    asm volatile("" ::: "memory");
+  }
+#undef FVQA_ROW
+#undef FVQA_DSR
+
+  // ---- epilogue (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
+  const int ccol = lane & 15;
+  const int crow = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int m = m0 + wr * 128 + i * 16 + crow + rg;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + ccol;
+        if (n >= N) continue;
+        float v = acc[i][j][rg];
+        if (SPLIT) {
+          ws[((size_t)sp * M + m) * N + n] = v;
+        } else if (tail != nullptr && m >= m_split) {
+          tail[(size_t)(m - m_split) * N + n] += v;
+        } else {
+          if (EPI == FVQA_EPI_RESIDUAL) v += to_f32<T>(R[(size_t)m * ldc + n]);
+          C[(size_t)m * ldc + n] = from_f32<TO>(v);
+        }
+      }
+    }
+  }
+}
+
+// out = sum_s ws[s] (+R); rows >= m_split accumulate into tail (fp32)
+template <typename T, typename TO, int EPI>
+__global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ ws, TO* __restrict__ C,
+                                                    const T* __restrict__ R, float* __restrict__ tail, int M, int N,
+                                                    int ldc, int m_split, int splits) {
+  const size_t n4 = (size_t)M * (N / 4);
+  const size_t plane = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / (N / 4));
+    const int n = (int)(i % (N / 4)) * 4;
+    float v[4];
+    Vec4<float>::load(ws + (size_t)m * N + n, v);
+    for (int s = 1; s < splits; ++s) {
+      float u[4];
+      Vec4<float>::load(ws + s * plane + (size_t)m * N + n, u);
+      v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+    }
+    if (tail != nullptr && m >= m_split) {
+      float* tp = tail + (size_t)(m - m_split) * N + n;
+      float u[4];
+      Vec4<float>::load(tp, u);
+      u[0] += v[0]; u[1] += v[1]; u[2] += v[2]; u[3] += v[3];
+      Vec4<float>::store(tp, u);
+    } else {
+      if (EPI == FVQA_EPI_RESIDUAL) {
+        float r[4];
+        Vec4<T>::load(R + (size_t)m * ldc + n, r);
+        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+      }
+      Vec4<TO>::store(C + (size_t)m * ldc + n, v);
+    }
+  }
+}
+
+template <typename T, typename TO, int EPI>
+int launch_256(const void* A, const void* B, void* C, const void* R, float* tail, float* ws, int M, int N, int K,
+               int lda, int ldb, int ldc, int m_split, int splits, hipStream_t st) {
+  const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
+  dim3 grid(tm * tn * splits), block(512);
+  if (splits > 1) {
+    auto k = gemm_nt_256<T, TO, EPI, true>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256); attr_done = true; }
+    hipLaunchKernelGGL(k, grid, block, LDS256, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
+                       lda, ldb, ldc, m_split, tm, splits);
+    size_t n4 = (size_t)M * (N / 4);
+    int g = (int)((n4 + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL((splitk_fixup<T, TO, EPI>), dim3(g), dim3(256), 0, st, (const float*)ws, (TO*)C, (const T*)R,
+                       tail, M, N, ldc, m_split, splits);
+  } else {
+    auto k = gemm_nt_256<T, TO, EPI, false>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256); attr_done = true; }
+    hipLaunchKernelGGL(k, grid, block, LDS256, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
+                       lda, ldb, ldc, m_split, tm, 1);
+  }
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+}  // namespace
+
+// how many K splits the 256-tile path uses for an (M, N, K) problem on a 256-CU part
+extern "C" int fvqa_gemm_splits(int M, int N, int K, int dtype) {
+  const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+  const int ke = dtype == FVQA_BF16 ? 32 : 16;
+  const int nk = K / ke;
+  int s = 256 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  if (s > 8) s = 8;
+  while (s > 1 && nk / s < 16) --s;       // keep >= 16 stages per split: the ring needs a run-up
+  return s;
+}
+
+extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
+  const int s = fvqa_gemm_splits(M, N, K, dtype);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, float* tail, void* ws,
+                          size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
+                          int out_dtype, int epilogue, int force_splits, hipStream_t st) {
+  int splits = force_splits > 0 ? force_splits : fvqa_gemm_splits(M, N, K, dtype);
+  if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3))) splits = 1;
+#define GO(T, TO)                                                                                              \
+  return epilogue == FVQA_EPI_RESIDUAL                                                                         \
+             ? launch_256<T, TO, FVQA_EPI_RESIDUAL>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc, m_split, \
+                                                    splits, st)                                                \
+             : launch_256<T, TO, FVQA_EPI_NONE>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc, m_split,  \
+                                                splits, st)
+  if (dtype == FVQA_BF16) {
+    if (out_dtype == FVQA_F32) { GO(bf16_t, float); }
+    GO(bf16_t, bf16_t);
+  }
+  GO(float, float);
+#undef GO
+}

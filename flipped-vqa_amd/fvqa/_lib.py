@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -20,7 +20,9 @@ _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 SIGNATURES = {
     "fvqa_version": (_i, []),
     "fvqa_arch": (C.c_char_p, []),
-    "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "fvqa_gemm_splits": (_i, [_i, _i, _i, _i]),
+    "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
     "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
     "fvqa_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fvqa_rope_qk": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -55,6 +55,19 @@ def _need(cond: bool, msg: str):
 
 
 # ------------------------------------------------------------------------------------ GEMM
+_GEMM_WS = {}
+
+
+def gemm_workspace(device, nbytes: int) -> torch.Tensor:
+    """One grow-only split-K scratch buffer per device (fp32 partial sums, reused by every GEMM
+    on the stream: launches are stream-ordered, so sharing is safe)."""
+    ws = _GEMM_WS.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _GEMM_WS[device] = ws
+    return ws
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
             tail: Optional[torch.Tensor] = None, m_split: int = 0, variant: int = 0) -> torch.Tensor:
     """out[M,N] = a[M,K] @ b[N,K]^T (+ residual). Rows >= m_split go to `tail` (fp32) when given."""
@@ -78,12 +91,21 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
         _need(residual.shape[1] == N and residual.shape[0] >= min(M, m_split), "gemm_nt: residual shape")
         epi = EPI_RESIDUAL
     lib = _lib.load()
+    code = dt_code(a.dtype)
+    if variant >= 16:
+        need = (variant - 16) * M * N * 4 if variant > 17 else 0
+    elif variant in (0, 3):
+        need = int(lib.fvqa_gemm_workspace(M, N, K, code))
+    else:
+        need = 0
+    ws = gemm_workspace(a.device, need) if need else None
     timing = GEMM_TIMING
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), _ptr(out), _ptr(residual), _ptr(tail), M, N, K, K, K, N, m_split,
-                          dt_code(a.dtype), dt_code(out.dtype), epi, variant, _stream())
+                          code, dt_code(out.dtype), epi, variant, _ptr(ws), ws.numel() if ws is not None else 0,
+                          _stream())
     if timing is not None:
         e1.record()
         key = f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_{'res' if epi else 'none'}"

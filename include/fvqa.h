@@ -49,11 +49,18 @@ const char* fvqa_arch(void); /* "gfx950"                                     */
  * autograd dX = dY·W of each (W frozen ⇒ no dW GEMM; the host keeps a transposed copy of
  * every frozen weight so dX is the same NT form).  A and B have `dtype`; C has `out_dtype`
  * (FVQA_F32 for LM-head logits). Rows m >= m_split (if tail != NULL) are written as fp32 to
- * tail[(m - m_split)*N + n] instead of C (adapter-query gradient rows).
- * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows. */
+ * tail[(m - m_split)*N + n] (ACCUMULATED, +=) instead of C (adapter-query gradient rows).
+ * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows.
+ * variant 0 picks the kernel: 256x256-tile 4-stage LDS-DMA ring (+ split-K through `workspace`
+ * when the output has too few tiles for 256 CUs) or the 128x128-tile kernel for small problems. */
 int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail,
                  int M, int N, int K, int lda, int ldb, int ldc, int m_split,
-                 int dtype, int out_dtype, int epilogue, int variant, void* stream);
+                 int dtype, int out_dtype, int epilogue, int variant,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* K-splits the 256x256 path picks for a problem (1 = none) and the fp32 partial-sum workspace
+ * ([splits][M][N]) it then needs; a too-small/NULL workspace silently falls back to 1 split. */
+int fvqa_gemm_splits(int M, int N, int K, int dtype);
+size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
 
 /* ---- RMSNorm (llama/model.py:37-42; used :185,186,347) -------------------------------- */
 int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int dim,

@@ -51,14 +51,36 @@ def test_gemm_nt(dtype, variant, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [3, 17, 18, 19, 20])          # 256x256 ring kernel: auto / 1..4 K-splits
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1034, 512, 1024), (300, 768, 2112), (1024, 4096, 4096)])
+def test_gemm_nt_256_ring_and_splitk(dtype, variant, M, N, K):
+    if (M, N, K) == (1024, 4096, 4096) and dtype == torch.float32 and variant not in (3, 20):
+        pytest.skip("fp32 big shape covered by two variants")
+    a, b = rnd(M, K, dtype=dtype, seed=11), rnd(N, K, dtype=dtype, scale=1 / math.sqrt(K), seed=12)
+    r = rnd(M, N, dtype=dtype, seed=13)
+    out = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out, residual=dev(r), variant=variant)
+    ref = a.double() @ b.double().T + r.double()
+    assert rel(out, ref) < tol(dtype, 5e-5, 1e-2)
+    split = M - 10
+    tail = torch.full((10, N), 2.0, dtype=torch.float32, device=DEV)
+    out2 = torch.zeros(split, N, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out2, tail=tail, m_split=split, variant=variant)
+    ref = a.double() @ b.double().T
+    assert rel(out2, ref[:split]) < tol(dtype, 5e-5, 1e-2)
+    assert rel(tail, ref[split:] + 2.0) < tol(dtype, 5e-5, 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_nt_identity_asymmetric(dtype):
     """A = I (padded) against an asymmetric B catches a transposed C write or a wrong k order."""
     M = N = K = 128
     a = torch.eye(M, K, dtype=dtype)
     b = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 0.5).to(dtype)     # exactly representable
-    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm_nt(dev(a), dev(b), out)
-    assert torch.equal(out.cpu(), b.float().T.contiguous())
+    for variant in (2, 3, 18):
+        out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        ops.gemm_nt(dev(a), dev(b), out, variant=variant)
+        assert torch.equal(out.cpu(), b.float().T.contiguous()), variant
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -31,7 +31,7 @@ constexpr int TM = 256, TN = 256;
 constexpr int SROW = 64;                 // bytes of K per row per stage
 constexpr int STAGE_OP = TM * SROW;      // 16 KiB per operand per stage
 constexpr int STAGE = 2 * STAGE_OP;      // 32 KiB
-constexpr int NSTAGE = 4;
+constexpr int NSTAGE = 4;                // ring depth of the plain loop (PIPE == 0)
 constexpr int LDS256 = NSTAGE * STAGE;   // 128 KiB
 
 template <typename T> struct Mma256;
@@ -59,7 +59,10 @@ __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
 }
 
 // EPI: 0 none, 1 residual. SPLIT: write fp32 partials to `ws` instead of C.
-template <typename T, typename TO, int EPI, bool SPLIT>
+// PIPE: 0 = plain ring loop (fragments read and consumed in the same stage);
+//       NS (4 or 5) = software-pipelined loop over an NS-deep ring: the fragments of stage t+1 are
+//       read into a second register set while the 32 MFMAs of stage t run.
+template <typename T, typename TO, int EPI, bool SPLIT, int PIPE>
 __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, const T* __restrict__ B,
                                                    TO* __restrict__ C, const T* __restrict__ R,
                                                    float* __restrict__ tail, float* __restrict__ ws, int M, int N,
@@ -76,8 +79,10 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
   const int tni = wid / (tiles_m * splits);
   const int m0 = tmi * TM, n0 = tni * TN;
   const int nk_all = K / KE;
-  const int kbeg = (int)(((long long)nk_all * sp) / splits);
-  const int kend = (int)(((long long)nk_all * (sp + 1)) / splits);
+  // K range of this split in stages; the wide-row loop eats stages in pairs, so its ranges are even
+  constexpr int KU = PIPE == 2 ? 2 : 1;
+  const int kbeg = KU * (int)(((long long)(nk_all / KU) * sp) / splits);
+  const int kend = KU * (int)(((long long)(nk_all / KU) * (sp + 1)) / splits);
   const int nk = kend - kbeg;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,15 +95,21 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int piece = w * 2 + t;
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 16)
+    // timing experiment only (results are garbage): every DMA instruction fetches whole 128-B lines
+    const int row = piece * 8 + (lane >> 3);
+    const int c = (lane & 7);
+#else
     const int row = piece * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
+#endif
     int ga = m0 + row; ga = ga < M ? ga : M - 1;
     int gb = n0 + row; gb = gb < N ? gb : N - 1;
     srcA[t] = A + (size_t)ga * lda + (size_t)kbeg * KE + c * CH;
     srcB[t] = B + (size_t)gb * ldb + (size_t)kbeg * KE + c * CH;
   }
-  auto issue = [&](int st) {                 // stage index st (relative to kbeg) -> ring slot st & 3
-    char* dA = smem + (st & (NSTAGE - 1)) * STAGE;
+  auto issue_slot = [&](int st, int slot) {  // stage index st (relative to kbeg) -> ring slot
+    char* dA = smem + slot * STAGE;
     char* dB = dA + STAGE_OP;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -109,6 +120,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
                                        (__attribute__((address_space(3))) void*)(dB + piece * 1024), 16, 0, 0);
     }
   };
+  auto issue = [&](int st) { issue_slot(st, st & (NSTAGE - 1)); };
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -122,43 +134,222 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
   const int offA = (wr * 128 + frow) * SROW + fch;
   const int offB = STAGE_OP + (wc * 64 + frow) * SROW + fch;
 
-  // prologue: three stages in flight
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // LDS fragment reads are inline asm on purpose: hipcc's waitcnt pass makes every compiler-visible
+  // LDS load wait for ALL in-flight LDS-DMA (s_waitcnt vmcnt(0)), which would drain the ring each
+  // stage. The reads return in issue order, so counted lgkmcnt waits release the MFMAs; each wait
+  // statement names the registers it guards ("+v") so no consumer is scheduled above it.
+#define FVQA_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define FVQA_READ12(A_, B_, slot)                                                                          \
+  {                                                                                                          \
+    const unsigned sb_ = lds0 + (unsigned)((slot) * STAGE);                                                  \
+    const unsigned pa_ = sb_ + (unsigned)offA, pb_ = sb_ + (unsigned)offB;                                   \
+    FVQA_DSR(B_[0], pb_, 0);    FVQA_DSR(B_[1], pb_, 1024); FVQA_DSR(B_[2], pb_, 2048); FVQA_DSR(B_[3], pb_, 3072); \
+    FVQA_DSR(A_[0], pa_, 0);    FVQA_DSR(A_[1], pa_, 1024); FVQA_DSR(A_[2], pa_, 2048); FVQA_DSR(A_[3], pa_, 3072); \
+    FVQA_DSR(A_[4], pa_, 4096); FVQA_DSR(A_[5], pa_, 5120); FVQA_DSR(A_[6], pa_, 6144); FVQA_DSR(A_[7], pa_, 7168); \
+  }
+  auto wait_dma = [&](int newer) {           // my DMA groups newer than the awaited one: 4 loads each
+    if (newer >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  if constexpr (PIPE == 2) {
+    // ---- wide-row ring: a stage is 128 bytes of K per row (64 bf16 / 32 fp32), so every DMA lane
+    // quad-pair fetches WHOLE 128-byte cache lines (the 64-byte-row loops issue one L2 request per
+    // half line: the L2 request rate, not bytes, bounded them). Stage = 32 KiB A + 32 KiB B, ring of
+    // two stages; each stage is consumed as two MFMA k-steps. Rows are XOR-swizzled by (row & 7)
+    // over their eight 16-byte chunks (conflict-free for ds_read_b128, as in gemm_nt_128).
+    constexpr int WROW = 128, WOP = TM * WROW, WSTAGE = 2 * WOP;
+    const int nw = nk / 2;                       // wide stages in this K range (host guarantees even)
+    const T* wA[4];
+    const T* wB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int piece = w * 4 + t;               // 32 pieces of 8 rows x 128 B per operand
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      int ga = m0 + row; ga = ga < M ? ga : M - 1;
+      int gb = n0 + row; gb = gb < N ? gb : N - 1;
+      wA[t] = A + (size_t)ga * lda + (size_t)kbeg * KE + c * CH;
+      wB[t] = B + (size_t)gb * ldb + (size_t)kbeg * KE + c * CH;
+    }
+    // one DMA piece (1 KiB) of stage u: q = 0..3 -> A pieces, 4..7 -> B pieces of this wave
+    auto issue_piece = [&](int u, int q) {
+      char* d = smem + (u & 1) * WSTAGE + (q >> 2) * WOP + (w * 4 + (q & 3)) * 1024;
+      const T* src = ((q >> 2) ? wB[q & 3] : wA[q & 3]) + (size_t)u * 2 * KE;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    };
+    auto issue_w = [&](int u) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) issue_piece(u, q);
+    };
+    const int fsw = lane & 7, fkc = lane >> 4;
+    const unsigned rowA = (unsigned)((wr * 128 + frow) * WROW);
+    const unsigned rowB = (unsigned)(WOP + (wc * 64 + frow) * WROW);
+    const unsigned ck0 = (unsigned)(((0 + fkc) ^ fsw) << 4), ck1 = (unsigned)(((4 + fkc) ^ fsw) << 4);
+#define FVQA_WREAD(A_, B_, sb, ck)                                                                           \
+  {                                                                                                          \
+    const unsigned pa_ = (sb) + rowA + (ck), pb_ = (sb) + rowB + (ck);                                       \
+    FVQA_DSR(B_[0], pb_, 0);    FVQA_DSR(B_[1], pb_, 2048);  FVQA_DSR(B_[2], pb_, 4096);  FVQA_DSR(B_[3], pb_, 6144);  \
+    FVQA_DSR(A_[0], pa_, 0);    FVQA_DSR(A_[1], pa_, 2048);  FVQA_DSR(A_[2], pa_, 4096);  FVQA_DSR(A_[3], pa_, 6144);  \
+    FVQA_DSR(A_[4], pa_, 8192); FVQA_DSR(A_[5], pa_, 10240); FVQA_DSR(A_[6], pa_, 12288); FVQA_DSR(A_[7], pa_, 14336); \
+  }
+#define FVQA_WROW(i, n)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
+  Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
+  Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
+  __builtin_amdgcn_sched_barrier(0);
+    // The eight DMA issues of the next stage are interleaved one per MFMA row of the first k-step
+    // (an LDS-DMA issue costs ~100 cycles of the wave's issue stream; behind an MFMA row it hides).
+#define FVQA_WROW_DMA(i, n, q)                                                         \
+  FVQA_WROW(i, n)                                                                      \
+  if (more) issue_piece(u + 1, q);                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+    if (nw > 0) issue_w(0);
+    for (int u = 0; u < nw; ++u) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA of stage u has landed
+      __builtin_amdgcn_s_barrier();                          // ... and everyone's; slot (u+1)&1 is free
+      asm volatile("" ::: "memory");
+      const bool more = u + 1 < nw;
+      const unsigned sb = lds0 + (unsigned)((u & 1) * WSTAGE);
+      {
+        u32x4 a[8], b[4];
+        FVQA_WREAD(a, b, sb, ck0);
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        FVQA_WROW_DMA(0, 7, 0) FVQA_WROW_DMA(1, 6, 4) FVQA_WROW_DMA(2, 5, 1) FVQA_WROW_DMA(3, 4, 5)
+        FVQA_WROW_DMA(4, 3, 2) FVQA_WROW_DMA(5, 2, 6) FVQA_WROW_DMA(6, 1, 3) FVQA_WROW_DMA(7, 0, 7)
+      }
+      {
+        u32x4 a[8], b[4];
+        FVQA_WREAD(a, b, sb, ck1);
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        FVQA_WROW(0, 7) FVQA_WROW(1, 6) FVQA_WROW(2, 5) FVQA_WROW(3, 4)
+        FVQA_WROW(4, 3) FVQA_WROW(5, 2) FVQA_WROW(6, 1) FVQA_WROW(7, 0)
+      }
+      asm volatile("" ::: "memory");
+    }
+#undef FVQA_WROW_DMA
+#undef FVQA_WROW
+#undef FVQA_WREAD
+  } else
+  if constexpr (PIPE == 0) {
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
   if (nk > 2) issue(2);
-
-  // LDS fragment reads are inline asm on purpose: hipcc's waitcnt pass makes every compiler-visible
-  // LDS load wait for ALL in-flight LDS-DMA (s_waitcnt vmcnt(0)), which would drain the ring each
-  // stage. The reads return in issue order, so counted lgkmcnt waits release the MFMAs row by row;
-  // each wait statement names the registers it guards ("+v") so no consumer is scheduled above it.
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-#define FVQA_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define FVQA_ROW(i, n)                                                                 \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
   Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
   Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
   __builtin_amdgcn_sched_barrier(0);
+#ifndef FVQA_ABLATE
+#define FVQA_ABLATE 0      /* tuning builds only: 1 no MFMA, 2 no in-loop DMA, 4 no LDS reads, 8 no barrier */
+#endif
   for (int t = 0; t < nk; ++t) {
-    // my own DMA for stage t has landed once at most (stages newer than t) * 4 loads are pending
-    const int newer = min(nk - t - 1, 2);
-    if (newer == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // stage t complete for all waves; slot (t-1)&3 is free
+    if (!(FVQA_ABLATE & 2)) wait_dma(min(nk - t - 1, 2));
+    if (!(FVQA_ABLATE & 8)) __builtin_amdgcn_s_barrier();   // stage t complete for all waves; slot (t-1)&3 free
     asm volatile("" ::: "memory");
-    if (t + 3 < nk) issue(t + 3);
-    const unsigned sb = lds0 + (unsigned)((t & (NSTAGE - 1)) * STAGE);
-    const unsigned pa = sb + (unsigned)offA, pb = sb + (unsigned)offB;
+    if (!(FVQA_ABLATE & 2) && t + 3 < nk) issue(t + 3);
     u32x4 a[8], b[4];
-    FVQA_DSR(b[0], pb, 0);    FVQA_DSR(b[1], pb, 1024); FVQA_DSR(b[2], pb, 2048); FVQA_DSR(b[3], pb, 3072);
-    FVQA_DSR(a[0], pa, 0);    FVQA_DSR(a[1], pa, 1024); FVQA_DSR(a[2], pa, 2048); FVQA_DSR(a[3], pa, 3072);
-    FVQA_DSR(a[4], pa, 4096); FVQA_DSR(a[5], pa, 5120); FVQA_DSR(a[6], pa, 6144); FVQA_DSR(a[7], pa, 7168);
-    asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-    FVQA_ROW(0, 7) FVQA_ROW(1, 6) FVQA_ROW(2, 5) FVQA_ROW(3, 4)
-    FVQA_ROW(4, 3) FVQA_ROW(5, 2) FVQA_ROW(6, 1) FVQA_ROW(7, 0)
+    if (FVQA_ABLATE & 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = u32x4{(unsigned)t, 1u, 2u, 3u};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = u32x4{(unsigned)t, 5u, 6u, 7u};
+    } else {
+      FVQA_READ12(a, b, (t & (NSTAGE - 1)));
+    }
+    if (FVQA_ABLATE & 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(b[j]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      FVQA_ROW(0, 7) FVQA_ROW(1, 6) FVQA_ROW(2, 5) FVQA_ROW(3, 4)
+      FVQA_ROW(4, 3) FVQA_ROW(5, 2) FVQA_ROW(6, 1) FVQA_ROW(7, 0)
+    }
     asm volatile("" ::: "memory");
   }
 #undef FVQA_ROW
+  } else {
+    // Software-pipelined loop. A stage is consumed in two halves of 16 MFMAs (output rows 0-63 and
+    // 64-127 of the wave); the LDS reads of the NEXT half are always issued before the MFMAs of the
+    // current half, so every counted lgkmcnt wait sits behind >= 256 MFMA cycles of cover:
+    //   top of stage t : [b, aL of stage t in flight]  read aH(t) ; wait(b,aL) ; 16 MFMA (rows 0-63)
+    //   middle         : wait my DMA(t+1) ; s_barrier ; issue DMA(t+NS-1) ; read b',aL'(t+1) ;
+    //                    wait(aH) ; 16 MFMA (rows 64-127)
+    // The barrier publishes stage t+1 and retires every wave's reads of stage t-1 (they were waited
+    // for before that wave's MFMAs of stage t-1), whose ring slot the new DMA overwrites.
+    constexpr int NS = PIPE;
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+      if (s0 < nk) issue_slot(s0, s0);
+    wait_dma(min(nk, NS - 1) - 1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 b0[4], b1[4], l0[4], l1[4], hh[4];
+#define FVQA_READ_H1(B_, L_, slot)                                                                          \
+  {                                                                                                          \
+    const unsigned sb_ = lds0 + (unsigned)((slot) * STAGE);                                                  \
+    const unsigned pa_ = sb_ + (unsigned)offA, pb_ = sb_ + (unsigned)offB;                                   \
+    FVQA_DSR(B_[0], pb_, 0); FVQA_DSR(B_[1], pb_, 1024); FVQA_DSR(B_[2], pb_, 2048); FVQA_DSR(B_[3], pb_, 3072); \
+    FVQA_DSR(L_[0], pa_, 0); FVQA_DSR(L_[1], pa_, 1024); FVQA_DSR(L_[2], pa_, 2048); FVQA_DSR(L_[3], pa_, 3072); \
+  }
+#define FVQA_READ_H2(H_, slot)                                                                              \
+  {                                                                                                          \
+    const unsigned pa_ = lds0 + (unsigned)((slot) * STAGE) + (unsigned)offA;                                 \
+    FVQA_DSR(H_[0], pa_, 4096); FVQA_DSR(H_[1], pa_, 5120); FVQA_DSR(H_[2], pa_, 6144); FVQA_DSR(H_[3], pa_, 7168); \
+  }
+#define FVQA_MMA16(A_, B_, r0)                                                                \
+  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+    Mma256<T>::run(A_[i_], B_[0], acc[r0 + i_][0]); Mma256<T>::run(A_[i_], B_[1], acc[r0 + i_][1]); \
+    Mma256<T>::run(A_[i_], B_[2], acc[r0 + i_][2]); Mma256<T>::run(A_[i_], B_[3], acc[r0 + i_][3]); \
+  }
+#define FVQA_STEP(CB, CL, NB, NL, MORE)                                                                      \
+  {                                                                                                          \
+    FVQA_READ_H2(hh, rs);                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(4)"                                                                      \
+                 : "+v"(CB[0]), "+v"(CB[1]), "+v"(CB[2]), "+v"(CB[3]), "+v"(CL[0]), "+v"(CL[1]), "+v"(CL[2]), \
+                   "+v"(CL[3]));                                                                             \
+    FVQA_MMA16(CL, CB, 0)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (MORE) {                                                                                              \
+      wait_dma(min(nk - t - 2, NS - 3));                                                                     \
+      __builtin_amdgcn_s_barrier();                                                                          \
+      asm volatile("" ::: "memory");                                                                         \
+      if (t + NS - 1 < nk) issue_slot(t + NS - 1, is);                                                       \
+      rs = (rs + 1 == NS) ? 0 : rs + 1;                                                                      \
+      FVQA_READ_H1(NB, NL, rs);                                                                              \
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hh[2]), "+v"(hh[3]));             \
+    } else {                                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hh[2]), "+v"(hh[3]));             \
+    }                                                                                                        \
+    is = (is + 1 == NS) ? 0 : is + 1;                                                                        \
+    FVQA_MMA16(hh, CB, 4)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    ++t;                                                                                                     \
+  }
+    int rs = 0;            // ring slot of stage t
+    int is = NS - 1;       // ring slot the next DMA goes to: (t + NS - 1) % NS
+    int t = 0;
+    if (nk > 0) {
+      FVQA_READ_H1(b0, l0, 0);
+      // two stages per trip so that the two fragment register sets alternate statically
+      while (t < nk) {
+        FVQA_STEP(b0, l0, b1, l1, (t + 1 < nk))
+        if (t < nk) FVQA_STEP(b1, l1, b0, l0, (t + 1 < nk))
+      }
+    }
+#undef FVQA_STEP
+#undef FVQA_MMA16
+#undef FVQA_READ_H2
+#undef FVQA_READ_H1
+  }
+#undef FVQA_READ12
 #undef FVQA_DSR
 
   // ---- epilogue (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
@@ -222,16 +413,17 @@ __global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ ws
   }
 }
 
-template <typename T, typename TO, int EPI>
+template <typename T, typename TO, int EPI, int PIPE>
 int launch_256(const void* A, const void* B, void* C, const void* R, float* tail, float* ws, int M, int N, int K,
                int lda, int ldb, int ldc, int m_split, int splits, hipStream_t st) {
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
   dim3 grid(tm * tn * splits), block(512);
+  constexpr int LDSB = (PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
   if (splits > 1) {
-    auto k = gemm_nt_256<T, TO, EPI, true>;
+    auto k = gemm_nt_256<T, TO, EPI, true, PIPE>;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256); attr_done = true; }
-    hipLaunchKernelGGL(k, grid, block, LDS256, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
+    hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
                        lda, ldb, ldc, m_split, tm, splits);
     size_t n4 = (size_t)M * (N / 4);
     int g = (int)((n4 + 255) / 256);
@@ -239,10 +431,10 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
     hipLaunchKernelGGL((splitk_fixup<T, TO, EPI>), dim3(g), dim3(256), 0, st, (const float*)ws, (TO*)C, (const T*)R,
                        tail, M, N, ldc, m_split, splits);
   } else {
-    auto k = gemm_nt_256<T, TO, EPI, false>;
+    auto k = gemm_nt_256<T, TO, EPI, false, PIPE>;
     static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS256); attr_done = true; }
-    hipLaunchKernelGGL(k, grid, block, LDS256, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
+    hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
                        lda, ldb, ldc, m_split, tm, 1);
   }
   FVQA_CHECK_LAUNCH();
@@ -268,21 +460,28 @@ extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
   return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
 }
 
+// mode: 0 = plain ring loop, 4 / 5 = software-pipelined loop over a 4- / 5-deep ring
 int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, float* tail, void* ws,
                           size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
-                          int out_dtype, int epilogue, int force_splits, hipStream_t st) {
+                          int out_dtype, int epilogue, int force_splits, int mode, hipStream_t st) {
   int splits = force_splits > 0 ? force_splits : fvqa_gemm_splits(M, N, K, dtype);
   if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3))) splits = 1;
-#define GO(T, TO)                                                                                              \
+#define GO2(T, TO, P)                                                                                          \
   return epilogue == FVQA_EPI_RESIDUAL                                                                         \
-             ? launch_256<T, TO, FVQA_EPI_RESIDUAL>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc, m_split, \
-                                                    splits, st)                                                \
-             : launch_256<T, TO, FVQA_EPI_NONE>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc, m_split,  \
-                                                splits, st)
+             ? launch_256<T, TO, FVQA_EPI_RESIDUAL, P>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc,    \
+                                                       m_split, splits, st)                                    \
+             : launch_256<T, TO, FVQA_EPI_NONE, P>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc,        \
+                                                   m_split, splits, st)
+#define GO(T, TO)                     \
+  if (mode == 2) { GO2(T, TO, 2); }   \
+  if (mode == 5) { GO2(T, TO, 5); }   \
+  if (mode == 4) { GO2(T, TO, 4); }   \
+  GO2(T, TO, 0)
   if (dtype == FVQA_BF16) {
     if (out_dtype == FVQA_F32) { GO(bf16_t, float); }
     GO(bf16_t, bf16_t);
   }
   GO(float, float);
 #undef GO
+#undef GO2
 }

@@ -39,7 +39,10 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=()) -> str:
+    """defines: extra -D macros (tuning builds write to a different `out`, always from scratch)."""
+    if defines:
+        return _build_variant(out, defines, verbose)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -65,6 +68,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if jobs or force or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
     return LIB
+
+
+def _build_variant(out, defines, verbose):
+    hipcc = _hipcc()
+    cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", out, *sources()]
+    if verbose:
+        print("[fvqa.build]", " ".join(cmd[-8:]), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed\n{r.stdout}\n{r.stderr}")
+    return out
 
 
 if __name__ == "__main__":

@@ -217,9 +217,9 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
 extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail, int M, int N,
                             int K, int lda, int ldb, int ldc, int m_split, int dtype, int out_dtype, int epilogue,
                             int variant, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!A || !B || !C) return FVQA_EINVAL;
+  if (!A || !B || (!C && epilogue != FVQA_EPI_PARTIAL)) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype) || !fvqa_dtype_ok(out_dtype)) return FVQA_EINVAL;
-  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL) return FVQA_EINVAL;
+  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_PARTIAL) return FVQA_EINVAL;
   if (epilogue == FVQA_EPI_RESIDUAL && (!R || out_dtype != dtype)) return FVQA_EINVAL;
   if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return FVQA_ESHAPE;
@@ -230,7 +230,7 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
     return FVQA_EALIGN;
   if (lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const bool big = (variant >= 3 && variant <= 7) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
+  const bool big = epilogue == FVQA_EPI_PARTIAL || (variant >= 3 && variant <= 7) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
   if (big) {
     const int mode = variant == 4 ? 0 : variant == 5 ? 4 : variant == 6 ? 5 : variant == 7 ? 2 : FVQA_GEMM256_DEFAULT_MODE;
     return fvqa_gemm_nt_256_impl(A, B, C, R, tail, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, m_split, dtype,

@@ -415,21 +415,23 @@ __global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ ws
 
 template <typename T, typename TO, int EPI, int PIPE>
 int launch_256(const void* A, const void* B, void* C, const void* R, float* tail, float* ws, int M, int N, int K,
-               int lda, int ldb, int ldc, int m_split, int splits, hipStream_t st) {
+               int lda, int ldb, int ldc, int m_split, int splits, bool partial_only, hipStream_t st) {
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
   dim3 grid(tm * tn * splits), block(512);
   constexpr int LDSB = (PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
-  if (splits > 1) {
+  if (splits > 1 || partial_only) {
     auto k = gemm_nt_256<T, TO, EPI, true, PIPE>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
     hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
                        lda, ldb, ldc, m_split, tm, splits);
-    size_t n4 = (size_t)M * (N / 4);
-    int g = (int)((n4 + 255) / 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL((splitk_fixup<T, TO, EPI>), dim3(g), dim3(256), 0, st, (const float*)ws, (TO*)C, (const T*)R,
-                       tail, M, N, ldc, m_split, splits);
+    if (!partial_only) {
+      size_t n4 = (size_t)M * (N / 4);
+      int g = (int)((n4 + 255) / 256);
+      if (g > 2048) g = 2048;
+      hipLaunchKernelGGL((splitk_fixup<T, TO, EPI>), dim3(g), dim3(256), 0, st, (const float*)ws, (TO*)C,
+                         (const T*)R, tail, M, N, ldc, m_split, splits);
+    }
   } else {
     auto k = gemm_nt_256<T, TO, EPI, false, PIPE>;
     static bool attr_done = false;
@@ -465,13 +467,18 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
                           size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
                           int out_dtype, int epilogue, int force_splits, int mode, hipStream_t st) {
   int splits = force_splits > 0 ? force_splits : fvqa_gemm_splits(M, N, K, dtype);
-  if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3))) splits = 1;
+  const bool partial = epilogue == FVQA_EPI_PARTIAL;
+  if (partial) {
+    if (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3)) return FVQA_EALIGN;
+  } else if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3))) {
+    splits = 1;
+  }
 #define GO2(T, TO, P)                                                                                          \
   return epilogue == FVQA_EPI_RESIDUAL                                                                         \
              ? launch_256<T, TO, FVQA_EPI_RESIDUAL, P>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc,    \
-                                                       m_split, splits, st)                                    \
+                                                       m_split, splits, false, st)                             \
              : launch_256<T, TO, FVQA_EPI_NONE, P>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc,        \
-                                                   m_split, splits, st)
+                                                   m_split, splits, partial, st)
 #define GO(T, TO)                     \
   if (mode == 2) { GO2(T, TO, 2); }   \
   if (mode == 5) { GO2(T, TO, 5); }   \

@@ -8,72 +8,154 @@ namespace {
 constexpr int ROWS_PER_BLOCK = 4;   // 4 waves per 256-thread workgroup
 
 // ---- RMSNorm (reference llama/model.py:37-42) ---------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w,
-                                                     T* __restrict__ y, float* __restrict__ rstd, int rows,
-                                                     int dim, float eps) {
-  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const T* xr = x + (size_t)row * dim;
-  float ss = 0.f;
-  for (int c = lane * 4; c < dim; c += 256) {
-    float v[4];
-    Vec4<T>::load(xr + c, v);
-    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-  }
-  ss = wave_sum(ss);
-  const float r = rsqrtf(ss / (float)dim + eps);
-  if (lane == 0 && rstd) rstd[row] = r;
-  T* yr = y + (size_t)row * dim;
-  for (int c = lane * 4; c < dim; c += 256) {
-    float v[4], g[4], o[4];
-    Vec4<T>::load(xr + c, v);
-    Vec4<T>::load(w + c, g);
+// One 256-thread workgroup per row; a thread owns 8-element chunks c = 8*tid + 2048*k, loaded once
+// with 16-byte (bf16) / 2x16-byte (fp32) vector loads and kept in registers across the reduction
+// (single pass over HBM). The *_sum variants take the row as split-K partial sums of the producing
+// GEMM (fp32 [splits][rows_total][dim]) — the GEMM fix-up pass is fused into the norm.
+constexpr int NORM_MAXK = 4;          // dim <= 8192
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const uint4 t = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+  v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xFFFF0000u);
+  v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xFFFF0000u);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 t;
+  t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+  t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+  t.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
+  t.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = t;
+}
+// row value = sum of split-K partials (fp32)
+__device__ __forceinline__ void load8_sum(const float* ws, int splits, size_t plane, float (&v)[8]) {
+  load8<float>(ws, v);
+  for (int s = 1; s < splits; ++s) {
+    float u[8];
+    load8<float>(ws + s * plane, u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = round_to<T>(v[i] * r) * g[i];   // .type_as(x) then * weight
-    Vec4<T>::store(yr + c, o);
+    for (int i = 0; i < 8; ++i) v[i] += u[i];
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ g, const T* __restrict__ x,
-                                                     const T* __restrict__ w, const float* __restrict__ rstd,
-                                                     const T* __restrict__ resid, T* __restrict__ dx, int rows,
-                                                     int dim) {
-  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const T* xr = x + (size_t)row * dim;
-  const T* gr = g + (size_t)row * dim;
-  float dot = 0.f;
-  for (int c = lane * 4; c < dim; c += 256) {
-    float xv[4], gv[4], wv[4];
-    Vec4<T>::load(xr + c, xv);
-    Vec4<T>::load(gr + c, gv);
-    Vec4<T>::load(w + c, wv);
+// SUM: x := round_T(resid + sum_s ws[s]) is also stored to `h` (the residual stream)
+template <typename T, bool SUM>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, const float* __restrict__ ws,
+                                                     int splits, size_t plane, const T* __restrict__ resid,
+                                                     const T* __restrict__ w, T* __restrict__ h,
+                                                     T* __restrict__ y, float* __restrict__ rstd, int dim,
+                                                     float eps) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)row * dim;
+  float xv[NORM_MAXK][8];
+  float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dot += gv[i] * wv[i] * xv[i];
-  }
-  dot = wave_sum(dot);
-  const float r = rstd[row];
-  const float k = r * r * r * dot / (float)dim;
-  const T* rr = resid ? resid + (size_t)row * dim : nullptr;
-  T* dr = dx + (size_t)row * dim;
-  for (int c = lane * 4; c < dim; c += 256) {
-    float xv[4], gv[4], wv[4], o[4];
-    Vec4<T>::load(xr + c, xv);
-    Vec4<T>::load(gr + c, gv);
-    Vec4<T>::load(w + c, wv);
+  for (int k = 0; k < NORM_MAXK; ++k) {
+    const int c = tid * 8 + k * 2048;
+    if (c < dim) {
+      if (SUM) {
+        float r[8];
+        load8_sum(ws + base + c, splits, plane, xv[k]);
+        load8<T>(resid + base + c, r);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = r * gv[i] * wv[i] - xv[i] * k;
-    if (rr) {
-      float rv[4];
-      Vec4<T>::load(rr + c, rv);
+        for (int i = 0; i < 8; ++i) xv[k][i] = round_to<T>(xv[k][i] + r[i]);
+        store8<T>(h + base + c, xv[k]);
+      } else {
+        load8<T>(x + base + c, xv[k]);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] += rv[i];
+      for (int i = 0; i < 8; ++i) ss += xv[k][i] * xv[k][i];
     }
-    Vec4<T>::store(dr + c, o);
+  }
+  ss = block_sum_256(ss, red);
+  const float r = rsqrtf(ss / (float)dim + eps);
+  if (tid == 0 && rstd) rstd[row] = r;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXK; ++k) {
+    const int c = tid * 8 + k * 2048;
+    if (c < dim) {
+      float g[8], o[8];
+      load8<T>(w + c, g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = round_to<T>(xv[k][i] * r) * g[i];   // .type_as(x) then * weight
+      store8<T>(y + base + c, o);
+    }
+  }
+}
+
+// SUM: the upstream gradient g is the sum of split-K partials (kept in fp32, never rounded)
+template <typename T, bool SUM>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ g, const float* __restrict__ ws,
+                                                     int splits, size_t plane, const T* __restrict__ x,
+                                                     const T* __restrict__ w, const float* __restrict__ rstd,
+                                                     const T* __restrict__ resid, T* __restrict__ dx, int dim) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)row * dim;
+  float xv[NORM_MAXK][8], gw[NORM_MAXK][8];
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXK; ++k) {
+    const int c = tid * 8 + k * 2048;
+    if (c < dim) {
+      float wv[8];
+      load8<T>(x + base + c, xv[k]);
+      if (SUM) load8_sum(ws + base + c, splits, plane, gw[k]);
+      else load8<T>(g + base + c, gw[k]);
+      load8<T>(w + c, wv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        gw[k][i] *= wv[i];
+        dot += gw[k][i] * xv[k][i];
+      }
+    }
+  }
+  dot = block_sum_256(dot, red);
+  const float r = rstd[row];
+  const float kk = r * r * r * dot / (float)dim;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXK; ++k) {
+    const int c = tid * 8 + k * 2048;
+    if (c < dim) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = r * gw[k][i] - xv[k][i] * kk;
+      if (resid) {
+        float rv[8];
+        load8<T>(resid + base + c, rv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += rv[i];
+      }
+      store8<T>(dx + base + c, o);
+    }
+  }
+}
+
+// tail[r, :] += sum_s ws[s][row0 + r, :]   (fp32 adapter-gradient rows riding under a split-K GEMM)
+__global__ __launch_bounds__(256) void sum_tail_k(const float* __restrict__ ws, int splits, size_t plane, int row0,
+                                                  float* __restrict__ tail, int dim) {
+  const size_t base = (size_t)(row0 + blockIdx.x) * dim;
+  float* t = tail + (size_t)blockIdx.x * dim;
+  for (int c = threadIdx.x * 8; c < dim; c += 2048) {
+    float v[8], u[8];
+    load8_sum(ws + base + c, splits, plane, v);
+    load8<float>(t + c, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] += v[i];
+    store8<float>(t + c, u);
   }
 }
 
@@ -219,14 +301,31 @@ inline int grid_for(size_t n_items) {
   if ((dtype) == FVQA_BF16) { typedef bf16_t T; __VA_ARGS__; } \
   else { typedef float T; __VA_ARGS__; }
 
+static inline int norm_dims_ok(int rows, int dim) {
+  return rows > 0 && dim > 0 && dim % 8 == 0 && dim <= 2048 * NORM_MAXK;
+}
+
 extern "C" int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int dim, float eps,
                                 int dtype, void* stream) {
   if (!x || !w || !y) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
-  if (rows <= 0 || dim <= 0 || dim % 4) return FVQA_ESHAPE;
-  dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(rmsnorm_fwd_k<T>, grid, block, 0, (hipStream_t)stream, (const T*)x,
-                                       (const T*)w, (T*)y, rstd, rows, dim, eps));
+  if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T, false>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)x, nullptr, 0, 0, nullptr, (const T*)w, nullptr, (T*)y, rstd, dim,
+                                       eps));
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_sumres_rmsnorm_fwd(const float* ws, int splits, size_t plane, const void* resid, const void* w,
+                                       void* h, void* y, float* rstd, int rows, int dim, float eps, int dtype,
+                                       void* stream) {
+  if (!ws || !resid || !w || !h || !y) return FVQA_EINVAL;
+  if (!fvqa_dtype_ok(dtype) || splits < 1) return FVQA_EINVAL;
+  if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                       nullptr, ws, splits, plane, (const T*)resid, (const T*)w, (T*)h, (T*)y, rstd,
+                                       dim, eps));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
@@ -235,10 +334,26 @@ extern "C" int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, con
                                 void* dx, int rows, int dim, int dtype, void* stream) {
   if (!g || !x || !w || !rstd || !dx) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
-  if (rows <= 0 || dim <= 0 || dim % 4) return FVQA_ESHAPE;
-  dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(rmsnorm_bwd_k<T>, grid, block, 0, (hipStream_t)stream, (const T*)g,
-                                       (const T*)x, (const T*)w, rstd, (const T*)resid, (T*)dx, rows, dim));
+  if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T, false>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)g, nullptr, 0, 0, (const T*)x, (const T*)w, rstd, (const T*)resid,
+                                       (T*)dx, dim));
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_sum_rmsnorm_bwd(const float* ws, int splits, size_t plane, const void* x, const void* w,
+                                    const float* rstd, const void* resid, void* dx, float* tail, int tail_rows,
+                                    int rows, int dim, int dtype, void* stream) {
+  if (!ws || !x || !w || !rstd || !dx) return FVQA_EINVAL;
+  if (!fvqa_dtype_ok(dtype) || splits < 1 || (tail_rows > 0 && !tail)) return FVQA_EINVAL;
+  if (!norm_dims_ok(rows, dim) || tail_rows < 0) return FVQA_ESHAPE;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                       nullptr, ws, splits, plane, (const T*)x, (const T*)w, rstd, (const T*)resid,
+                                       (T*)dx, dim));
+  if (tail_rows > 0)
+    hipLaunchKernelGGL(sum_tail_k, dim3(tail_rows), dim3(256), 0, (hipStream_t)stream, ws, splits, plane, rows, tail,
+                       dim);
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }

@@ -11,8 +11,8 @@ import os
 from typing import Optional
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_RESIDUAL = 0, 1
-ABI_VERSION = 2
+EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL = 0, 1, 2
+ABI_VERSION = 3
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -25,6 +25,8 @@ SIGNATURES = {
     "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
     "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
     "fvqa_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "fvqa_sumres_rmsnorm_fwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),
+    "fvqa_sum_rmsnorm_bwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fvqa_rope_qk": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_swiglu_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "fvqa_swiglu_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),

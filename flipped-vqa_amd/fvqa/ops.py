@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_NONE, EPI_RESIDUAL, F32
+from ._lib import BF16, EPI_NONE, EPI_PARTIAL, EPI_RESIDUAL, F32
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _DTN = {torch.float32: "f32", torch.bfloat16: "bf16"}
@@ -114,7 +114,65 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
     return out
 
 
+def gemm_nt_partial(a: torch.Tensor, b: torch.Tensor):
+    """a[M,K] @ b[N,K]^T left as fp32 split-K partial sums: returns (ws, splits) with ws a
+    (splits, M, N) fp32 view of the shared GEMM workspace, to be consumed by sumres_rmsnorm_fwd /
+    sum_rmsnorm_bwd before the next GEMM on the stream."""
+    _dev(a, b)
+    _need(a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.dtype == b.dtype, "gemm_nt_partial: shapes")
+    M, K = a.shape
+    N = b.shape[0]
+    lib = _lib.load()
+    code = dt_code(a.dtype)
+    splits = int(lib.fvqa_gemm_splits(M, N, K, code))
+    need = splits * M * N * 4
+    ws = gemm_workspace(a.device, need)
+    timing = GEMM_TIMING
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), None, None, None, M, N, K, K, K, N, M, code, code, EPI_PARTIAL, 0,
+                          _ptr(ws), ws.numel(), _stream())
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[a.dtype]}_none"))
+    _lib.check(rc, "fvqa_gemm_nt(partial)")
+    return ws[:need].view(torch.float32).view(splits, M, N), splits
+
+
 # ------------------------------------------------------------------------------------ row ops
+def sumres_rmsnorm_fwd(ws, resid, w, h, y, rstd, eps: float, rows: int):
+    """h = round(resid + sum_s ws[s]); y = RMSNorm(h) * w  (first `rows` rows)."""
+    _dev(ws, resid, w, h, y, rstd)
+    splits, Mt, dim = ws.shape
+    _need(ws.dtype == torch.float32 and rows <= Mt, "sumres_rmsnorm_fwd: ws")
+    _need(resid.dtype == w.dtype == h.dtype == y.dtype and w.numel() == dim, "sumres_rmsnorm_fwd: dtype")
+    for t in (resid, h, y):
+        _need(t.shape[-1] == dim and t.numel() >= rows * dim, "sumres_rmsnorm_fwd: rows")
+    _need(rstd.dtype == torch.float32 and rstd.numel() >= rows, "sumres_rmsnorm_fwd: rstd")
+    rc = _lib.load().fvqa_sumres_rmsnorm_fwd(_ptr(ws), splits, Mt * dim, _ptr(resid), _ptr(w), _ptr(h), _ptr(y),
+                                             _ptr(rstd), rows, dim, float(eps), dt_code(h.dtype), _stream())
+    _lib.check(rc, "fvqa_sumres_rmsnorm_fwd")
+
+
+def sum_rmsnorm_bwd(ws, x, w, rstd, dx, rows: int, resid=None, tail=None):
+    """dx = resid + rmsnorm_bwd(sum_s ws[s]); partial rows >= `rows` are added into `tail` (fp32)."""
+    _dev(ws, x, w, rstd, dx, resid, tail)
+    splits, Mt, dim = ws.shape
+    tail_rows = 0 if tail is None else Mt - rows
+    _need(ws.dtype == torch.float32 and rows <= Mt, "sum_rmsnorm_bwd: ws")
+    _need(x.dtype == w.dtype == dx.dtype and w.numel() == dim, "sum_rmsnorm_bwd: dtype")
+    for t in (x, dx, resid):
+        _need(t is None or (t.dtype == x.dtype and t.shape[-1] == dim and t.numel() >= rows * dim), "sum_rmsnorm_bwd: rows")
+    _need(rstd.dtype == torch.float32 and rstd.numel() >= rows, "sum_rmsnorm_bwd: rstd")
+    _need(tail is None or (tail.dtype == torch.float32 and tuple(tail.shape) == (tail_rows, dim) and tail_rows > 0),
+          "sum_rmsnorm_bwd: tail")
+    rc = _lib.load().fvqa_sum_rmsnorm_bwd(_ptr(ws), splits, Mt * dim, _ptr(x), _ptr(w), _ptr(rstd), _ptr(resid),
+                                          _ptr(dx), _ptr(tail), tail_rows, rows, dim, dt_code(x.dtype), _stream())
+    _lib.check(rc, "fvqa_sum_rmsnorm_bwd")
+
+
+
 def rmsnorm_fwd(x, w, y, rstd, eps: float, rows: Optional[int] = None):
     _dev(x, w, y, rstd)
     dim = x.shape[-1]

@@ -214,21 +214,26 @@ class StepEngine:
                 ops.embed_splice(ids[t], pk.emb, vf_tok, h0, B, S, F, vstart=vs[t], mode=0)
 
         adapter = m.adapter_query.weight.data.view(-1, A, D)     # (adapter_layer, A, D); model.py:304
+        # WO and W2 have N = D outputs (few tiles): their GEMMs leave fp32 split-K partials and the
+        # following "residual add + RMSNorm" kernel sums them (no separate fix-up pass, no extra
+        # round trip of the residual stream through HBM).
+        ops.rmsnorm_fwd(ar.xs[0], pk.an[0], ar.xn, ar.rstd1[0], self.eps, rows=R)
         for i in range(L):
             x = ar.xs[i]
-            ops.rmsnorm_fwd(x, pk.an[i], ar.xn, ar.rstd1[i], self.eps, rows=R)
             ops.cast_rows(adapter[i], ar.xn[R:Ra])
             ops.gemm_nt(ar.xn, pk.wqkv[i], ar.qkv[i])
             ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
             g1, g2 = m.gate_views(i)
             ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
-            ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)
-            ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
+            ws, _ = ops.gemm_nt_partial(ar.o[i], pk.wo[i])
+            ops.sumres_rmsnorm_fwd(ws, x, pk.fn[i], ar.h[i], ar.hn, ar.rstd2[i], self.eps, R)
             ops.gemm_nt(ar.hn, pk.w13[i], ar.ab[i])
             ops.swiglu_fwd(ar.ab[i], ar.z, R, Hf)
-            ops.gemm_nt(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i])
-
-        ops.rmsnorm_fwd(ar.xs[L], pk.norm, ar.xnf, ar.rstdN, self.eps, rows=R)
+            ws, _ = ops.gemm_nt_partial(ar.z, pk.w2[i])
+            if i + 1 < L:
+                ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.an[i + 1], ar.xs[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, R)
+            else:
+                ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.norm, ar.xs[L], ar.xnf, ar.rstdN, self.eps, R)
         n_lm = ar.n_lm
         ops.gemm_nt(ar.xnf[: n_lm * S], pk.wout, ar.logits)
         ar.loss_sum.zero_()
@@ -275,16 +280,16 @@ class StepEngine:
         for i in reversed(range(L)):
             ops.gemm_nt(cur, pk.w2_t[i], ar.dz)
             ops.swiglu_bwd(ar.dz, ar.ab[i], ar.dab, R, Hf)
-            ops.gemm_nt(ar.dab, pk.w13_t[i], ar.dhn)
-            ops.rmsnorm_bwd(ar.dhn, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
+            ws, _ = ops.gemm_nt_partial(ar.dab, pk.w13_t[i])
+            ops.sum_rmsnorm_bwd(ws, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, R, resid=cur)
             ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)
             g1, g2 = m.gate_views(i)
             dg1, dg2 = grads.gate_grad_views(i)
             ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1, dg2,
                          ar.attn_ws, n_seq, S, H, Dh, A, F)
             ops.rope_qk(ar.dqkv, self.cos, self.sin, n_seq, S, H, Dh, inverse=True)
-            ops.gemm_nt(ar.dqkv, pk.wqkv_t[i], ar.dxn, tail=g_adapter[i], m_split=R)
-            ops.rmsnorm_bwd(ar.dxn, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, resid=ar.dh, rows=R)
+            ws, _ = ops.gemm_nt_partial(ar.dqkv, pk.wqkv_t[i])
+            ops.sum_rmsnorm_bwd(ws, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, R, resid=ar.dh, tail=g_adapter[i])
             cur, nxt = nxt, cur
         for k, t in enumerate(self.tasks):
             dh0 = cur[k * B * S:(k + 1) * B * S]

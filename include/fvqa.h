@@ -39,6 +39,9 @@ extern "C" {
 /* GEMM epilogue selector */
 #define FVQA_EPI_NONE 0
 #define FVQA_EPI_RESIDUAL 1 /* C = acc + R                                  */
+#define FVQA_EPI_PARTIAL 2  /* no C: leave the fp32 split-K partial sums [splits][M][N] in
+                               `workspace` for a fused consumer (fvqa_sumres_rmsnorm_fwd,
+                               fvqa_sum_rmsnorm_bwd); splits = fvqa_gemm_splits(M,N,K,dtype) */
 
 int fvqa_version(void);      /* ABI version, bumped on any signature change */
 const char* fvqa_arch(void); /* "gfx950"                                     */
@@ -68,6 +71,17 @@ int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int row
 /* dx = (resid ? resid : 0) + rmsnorm_bwd(g; x, w, rstd)   (weight frozen ⇒ no dw) */
 int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, const float* rstd,
                      const void* resid, void* dx, int rows, int dim, int dtype, void* stream);
+
+/* Fused consumers of FVQA_EPI_PARTIAL GEMMs (plane = M_total*dim elements between splits):
+ * h = round(resid + sum_s ws[s]) (the residual stream, llama/model.py:185-186), y = RMSNorm(h)*w */
+int fvqa_sumres_rmsnorm_fwd(const float* ws, int splits, size_t plane, const void* resid,
+                            const void* w, void* h, void* y, float* rstd, int rows, int dim,
+                            float eps, int dtype, void* stream);
+/* dx = resid + rmsnorm_bwd(sum_s ws[s]; x, w, rstd); rows [rows, rows+tail_rows) of the partials
+ * are added into the fp32 `tail` (adapter-query gradient rows) */
+int fvqa_sum_rmsnorm_bwd(const float* ws, int splits, size_t plane, const void* x, const void* w,
+                         const float* rstd, const void* resid, void* dx, float* tail, int tail_rows,
+                         int rows, int dim, int dtype, void* stream);
 
 /* ---- RoPE on the q and k column blocks of a fused qkv buffer (llama/model.py:61-67,96).
  * qkv is (rows, 3*dim) with q at cols [0,dim), k at [dim,2dim). cos/sin are (S, head_dim/2)

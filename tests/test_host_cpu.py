@@ -28,7 +28,7 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fvqa_version() == _lib.ABI_VERSION
     assert lib.fvqa_arch() == b"gfx950"
     # argument validation happens before any launch: callable without a GPU
-    assert lib.fvqa_gemm_nt(None, None, None, None, None, 1, 1, 64, 64, 64, 1, 1, 1, 1, 0, 0, None) == -1
+    assert lib.fvqa_gemm_nt(None, None, None, None, None, 1, 1, 64, 64, 64, 1, 1, 1, 1, 0, 0, None, 0, None) == -1
     assert lib.fvqa_attn_bwd_workspace(2, 128, 32, 128, 10) > 0
     assert lib.fvqa_attn_bwd_workspace(2, 128, 32, 64, 10) == 0      # head_dim != 128 unsupported
 

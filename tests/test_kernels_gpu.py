@@ -132,6 +132,36 @@ def test_rmsnorm(dtype, rows, dim):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,tail", [(266, 256, 512, 10), (1034, 4096, 1024, 10), (128, 512, 2048, 0)])
+def test_partial_gemm_with_fused_norm_consumers(dtype, M, N, K, tail):
+    """GEMM left as fp32 split-K partials, consumed by residual+RMSNorm (fwd) and RMSNorm-bwd (+tail rows)."""
+    R = M - tail
+    a, b = rnd(M, K, dtype=dtype, seed=21), rnd(N, K, dtype=dtype, scale=1 / math.sqrt(K), seed=22)
+    res, w = rnd(R, N, dtype=dtype, seed=23), (rnd(N, dtype=dtype, scale=0.1, seed=24).float() + 1).to(dtype)
+    prod = a.double() @ b.double().T
+    ws, splits = ops.gemm_nt_partial(dev(a), dev(b))
+    assert tuple(ws.shape) == (splits, M, N)
+    assert rel(ws.sum(0), prod) < tol(dtype, 5e-5, 2e-3)
+    h = torch.empty(R, N, dtype=dtype, device=DEV)
+    y = torch.empty(R, N, dtype=dtype, device=DEV)
+    rstd = torch.empty(R, dtype=torch.float32, device=DEV)
+    ops.sumres_rmsnorm_fwd(ws, dev(res), dev(w), h, y, rstd, 1e-6, R)
+    href = prod[:R] + res.double()
+    assert rel(h, href) < tol(dtype, 5e-5, 1e-2)
+    yr, rr = ref_cpu.rmsnorm_fwd(h.double().cpu(), w.double(), 1e-6)      # norm of the STORED residual stream
+    assert rel(y, yr) < tol(dtype) and rel(rstd, rr[:, 0]) < 1e-5
+    x = rnd(R, N, dtype=dtype, seed=25)
+    xr, xrs = ref_cpu.rmsnorm_fwd(x.double(), w.double(), 1e-6)
+    dx = torch.empty(R, N, dtype=dtype, device=DEV)
+    tl = torch.full((tail, N), 3.0, device=DEV) if tail else None
+    ops.sum_rmsnorm_bwd(ws, dev(x), dev(w), dev(xrs[:, 0].float()), dx, R, resid=dev(res), tail=tl)
+    want = ref_cpu.rmsnorm_bwd(prod[:R], x.double(), w.double(), xrs) + res.double()
+    assert rel(dx, want) < tol(dtype, 5e-5, 1e-2)
+    if tail:
+        assert rel(tl, prod[R:] + 3.0) < tol(dtype, 5e-5, 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_rope(dtype):
     N, S, H, Dh = 2, 24, 3, 128
     D = H * Dh

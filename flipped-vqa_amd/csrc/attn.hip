@@ -14,6 +14,7 @@
 // Backward = two kernels (dQ by query rows; dK/dV by key rows, with the batch-summed adapter
 // key/value gradient as an extra key block) + a deterministic reduce; no float atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -470,6 +471,18 @@ inline int check_dims(int n_seq, int S, int H, int head_dim, int A, int F) {
 
 }  // namespace
 
+// bf16 production build on the matrix cores (attn_mfma.hip); FVQA_ATTN_VALU=1 keeps the vector build
+int fvqa_attn_fwd_mfma(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1, const float* gate2,
+                       const int32_t* vstart, int n_seq, int S, int H, int A, int F, hipStream_t st);
+int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const float* lse_a, const float* lse_t,
+                       const float* gate1, const float* gate2, const int32_t* vstart, void* dqkv, float* delta_a,
+                       float* delta_t, float* gate_part, float* dka, float* dva, int n_seq, int S, int H, int A, int F,
+                       hipStream_t st);
+static bool use_mfma_attention() {
+  static const bool v = [] { const char* e = getenv("FVQA_ATTN_VALU"); return !(e && e[0] == '1'); }();
+  return v;
+}
+
 extern "C" int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1,
                              const float* gate2, const int32_t* vstart, int n_seq, int seq_len, int n_heads,
                              int head_dim, int adapter_len, int max_feats, int dtype, void* stream) {
@@ -480,6 +493,12 @@ extern "C" int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_
   const int nqb = (seq_len + TILE - 1) / TILE;
   dim3 grid(nqb, n_heads, n_seq), block(256);
   const size_t lds = (size_t)(2 * TILE + 2 * adapter_len) * DH * sizeof(float);
+  if (dtype == FVQA_BF16 && use_mfma_attention()) {
+    fvqa_attn_fwd_mfma(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, seq_len, n_heads, adapter_len, max_feats,
+                       (hipStream_t)stream);
+    FVQA_CHECK_LAUNCH();
+    return FVQA_OK;
+  }
   if (dtype == FVQA_BF16)
     hipLaunchKernelGGL(attn_fwd_k<bf16_t>, grid, block, lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o,
                        lse_a, lse_t, gate1, gate2, vstart, n_seq, seq_len, n_heads, adapter_len, max_feats);
@@ -519,6 +538,14 @@ extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, co
   dim3 block(256);
   const size_t lds_q = (size_t)(2 * TILE + 2 * adapter_len) * DH * sizeof(float);
   const size_t lds_kv = (size_t)(2 * TILE * DH + 2 * TILE) * sizeof(float);
+  if (dtype == FVQA_BF16 && use_mfma_attention()) {
+    fvqa_attn_bwd_mfma(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, delta_a, delta_t, gate_part, dka, dva,
+                       n_seq, seq_len, n_heads, adapter_len, max_feats, st);
+    hipLaunchKernelGGL(attn_bwd_reduce_k<bf16_t>, dim3(64), block, 0, st, dka, dva, gate_part, gate1, (bf16_t*)dqkv,
+                       dgate1, dgate2, n_seq, seq_len, n_heads, adapter_len, nqb);
+    FVQA_CHECK_LAUNCH();
+    return FVQA_OK;
+  }
   if (dtype == FVQA_BF16) {
     typedef bf16_t T;
     hipLaunchKernelGGL(attn_bwd_dq_k<T>, dim3(nqb, n_heads, n_seq), block, lds_q, st, (const T*)d_o, (const T*)qkv,

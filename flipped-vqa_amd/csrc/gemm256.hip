@@ -77,10 +77,14 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
   const int tmi = wid % tiles_m;
   const int sp = (wid / tiles_m) % splits;
   const int tni = wid / (tiles_m * splits);
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 32)
+  const int m0 = 0, n0 = 0;      // timing experiment: every workgroup streams the same (L2-resident) tiles
+#else
   const int m0 = tmi * TM, n0 = tni * TN;
+#endif
   const int nk_all = K / KE;
   // K range of this split in stages; the wide-row loop eats stages in pairs, so its ranges are even
-  constexpr int KU = PIPE == 2 ? 2 : 1;
+  constexpr int KU = (PIPE == 2 || PIPE == 3) ? 2 : 1;
   const int kbeg = KU * (int)(((long long)(nk_all / KU) * sp) / splits);
   const int kend = KU * (int)(((long long)(nk_all / KU) * (sp + 1)) / splits);
   const int nk = kend - kbeg;
@@ -155,6 +159,101 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
+  if constexpr (PIPE == 3) {
+    // ---- wide-row asymmetric rings. Measured on MI355X (profiles/r01_gemm_ablation.log): with every
+    // workgroup streaming the same L2-resident tiles the DMA path alone runs 1.8 PF/s-equivalent, on
+    // the real operands 1.2 — the ring was waiting on HBM latency of the once-read WEIGHT panel, not
+    // on bandwidth. So the weight (B) operand gets a deeper ring than the activations (A, re-read
+    // by every N tile, served by L2 / Infinity Cache): A 2 x 32 KiB, B 3 x 32 KiB = 160 KiB.
+    // vmcnt retires in order per wave, so the two streams are issued by DIFFERENT waves: waves 0-3
+    // move A and wait vmcnt(0) for stage u; waves 4-7 move B two stages ahead and wait with one
+    // newer stage (8 loads) still in flight. One barrier per stage publishes both.
+    constexpr int WROW = 128, WOP = TM * WROW;            // 32 KiB per operand per stage
+    const int nw = nk / 2;
+    const bool bwave = w >= 4;                            // wave-uniform DMA role
+    const int wq = w & 3;
+    const T* wsrc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int piece = wq * 8 + t;                       // 32 pieces of 8 rows x 128 B per operand
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      int ga = m0 + row; ga = ga < M ? ga : M - 1;
+      int gb = n0 + row; gb = gb < N ? gb : N - 1;
+      wsrc[t] = bwave ? B + (size_t)gb * ldb + (size_t)kbeg * KE + c * CH
+                      : A + (size_t)ga * lda + (size_t)kbeg * KE + c * CH;
+    }
+    char* const ringA = smem;                             // 2 slots
+    char* const ringB = smem + 2 * WOP;                   // 3 slots
+    // piece q (0..7) of this wave's operand for stage u; slot = ring slot of that stage
+    auto issue_piece = [&](int u, int slot, int q) {
+      char* d = (bwave ? ringB : ringA) + slot * WOP + (wq * 8 + q) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + (size_t)u * 2 * KE),
+                                       (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    };
+    const int fsw = lane & 7, fkc = lane >> 4;
+    const unsigned rowA = (unsigned)((wr * 128 + frow) * WROW);
+    const unsigned rowB = (unsigned)(2 * WOP + (wc * 64 + frow) * WROW);
+    const unsigned ck0 = (unsigned)(((0 + fkc) ^ fsw) << 4), ck1 = (unsigned)(((4 + fkc) ^ fsw) << 4);
+#define FVQA_WREAD(A_, B_, pa0, pb0, ck)                                                                     \
+  {                                                                                                          \
+    const unsigned pa_ = (pa0) + (ck), pb_ = (pb0) + (ck);                                                   \
+    FVQA_DSR(B_[0], pb_, 0);    FVQA_DSR(B_[1], pb_, 2048);  FVQA_DSR(B_[2], pb_, 4096);  FVQA_DSR(B_[3], pb_, 6144);  \
+    FVQA_DSR(A_[0], pa_, 0);    FVQA_DSR(A_[1], pa_, 2048);  FVQA_DSR(A_[2], pa_, 4096);  FVQA_DSR(A_[3], pa_, 6144);  \
+    FVQA_DSR(A_[4], pa_, 8192); FVQA_DSR(A_[5], pa_, 10240); FVQA_DSR(A_[6], pa_, 12288); FVQA_DSR(A_[7], pa_, 14336); \
+  }
+#define FVQA_WROW(i, n)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
+  Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
+  Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
+  __builtin_amdgcn_sched_barrier(0);
+#define FVQA_WROW_DMA(i, n, q)                                                         \
+  FVQA_WROW(i, n)                                                                      \
+  if (more) issue_piece(nu, nslot, q);                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+    // prologue: A stage 0; B stages 0 and 1
+    if (nw > 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) issue_piece(0, 0, q);
+      if (bwave && nw > 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_piece(1, 1, q);
+      }
+    }
+    int sa = 0, sbs = 0;                                  // ring slots of stage u: u % 2, u % 3
+    for (int u = 0; u < nw; ++u) {
+      if (bwave && u + 1 < nw) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // B(u) landed, B(u+1) in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // stage u published; slots of stage u-1 are free
+      asm volatile("" ::: "memory");
+      // next DMA of this wave: A(u+1) -> A slot (u+1)%2, or B(u+2) -> B slot (u+2)%3
+      const int nu = bwave ? u + 2 : u + 1;
+      const int nslot = bwave ? (sbs == 0 ? 2 : sbs - 1) : (sa ^ 1);
+      const bool more = nu < nw;
+      const unsigned pa0 = lds0 + (unsigned)(sa * WOP) + rowA;
+      const unsigned pb0 = lds0 + (unsigned)(sbs * WOP) + rowB;
+      {
+        u32x4 a[8], b[4];
+        FVQA_WREAD(a, b, pa0, pb0, ck0);
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        FVQA_WROW_DMA(0, 7, 0) FVQA_WROW_DMA(1, 6, 1) FVQA_WROW_DMA(2, 5, 2) FVQA_WROW_DMA(3, 4, 3)
+        FVQA_WROW_DMA(4, 3, 4) FVQA_WROW_DMA(5, 2, 5) FVQA_WROW_DMA(6, 1, 6) FVQA_WROW_DMA(7, 0, 7)
+      }
+      {
+        u32x4 a[8], b[4];
+        FVQA_WREAD(a, b, pa0, pb0, ck1);
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        FVQA_WROW(0, 7) FVQA_WROW(1, 6) FVQA_WROW(2, 5) FVQA_WROW(3, 4)
+        FVQA_WROW(4, 3) FVQA_WROW(5, 2) FVQA_WROW(6, 1) FVQA_WROW(7, 0)
+      }
+      asm volatile("" ::: "memory");
+      sa ^= 1;
+      sbs = (sbs == 2) ? 0 : sbs + 1;
+    }
+#undef FVQA_WROW_DMA
+#undef FVQA_WROW
+#undef FVQA_WREAD
+  } else
   if constexpr (PIPE == 2) {
     // ---- wide-row ring: a stage is 128 bytes of K per row (64 bf16 / 32 fp32), so every DMA lane
     // quad-pair fetches WHOLE 128-byte cache lines (the 64-byte-row loops issue one L2 request per
@@ -197,11 +296,18 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     FVQA_DSR(A_[0], pa_, 0);    FVQA_DSR(A_[1], pa_, 2048);  FVQA_DSR(A_[2], pa_, 4096);  FVQA_DSR(A_[3], pa_, 6144);  \
     FVQA_DSR(A_[4], pa_, 8192); FVQA_DSR(A_[5], pa_, 10240); FVQA_DSR(A_[6], pa_, 12288); FVQA_DSR(A_[7], pa_, 14336); \
   }
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 1)
+#define FVQA_WROW(i, n)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
+  asm volatile("" ::"v"(a[i]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));            \
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #define FVQA_WROW(i, n)                                                                \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
   Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
   Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
   __builtin_amdgcn_sched_barrier(0);
+#endif
     // The eight DMA issues of the next stage are interleaved one per MFMA row of the first k-step
     // (an LDS-DMA issue costs ~100 cycles of the wave's issue stream; behind an MFMA row it hides).
 #define FVQA_WROW_DMA(i, n, q)                                                         \
@@ -418,7 +524,7 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
                int lda, int ldb, int ldc, int m_split, int splits, bool partial_only, hipStream_t st) {
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
   dim3 grid(tm * tn * splits), block(512);
-  constexpr int LDSB = (PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
+  constexpr int LDSB = (PIPE == 3 ? 5 : PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
   if (splits > 1 || partial_only) {
     auto k = gemm_nt_256<T, TO, EPI, true, PIPE>;
     static bool attr_done = false;
@@ -457,9 +563,34 @@ extern "C" int fvqa_gemm_splits(int M, int N, int K, int dtype) {
   return s;
 }
 
+// Tail-round plan for outputs with MORE tiles than CUs: the tiles of the last, partially filled
+// round (whole N-tile columns) are computed by a second launch that splits K, so the launch pair
+// takes 1 + 1/sr rounds instead of 2 (e.g. W1|W3: 344 tiles -> 256 + 88 x 2 halves).
+struct TailPlan { int n1; int sr; };
+static TailPlan tail_plan(int M, int N, int K, int dtype) {
+  TailPlan p = {N, 1};
+  const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
+  const int tiles = tm * tn;
+  if (tiles <= 256 || (256 % tm) != 0 || (N % TN) != 0) return p;
+  const int cols_per_round = 256 / tm;
+  const int rounds = tn / cols_per_round;
+  const int rem_cols = tn - rounds * cols_per_round;
+  if (rounds < 1 || rem_cols == 0) return p;
+  int sr = 256 / (rem_cols * tm);
+  if (sr > 4) sr = 4;
+  const int nk = K / (dtype == FVQA_BF16 ? 32 : 16);
+  while (sr > 1 && nk / sr < 16) --sr;
+  if (sr < 2) return p;
+  p.n1 = rounds * cols_per_round * TN;
+  p.sr = sr;
+  return p;
+}
+
 extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
   const int s = fvqa_gemm_splits(M, N, K, dtype);
-  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+  if (s > 1) return (size_t)s * M * N * sizeof(float);
+  const TailPlan p = tail_plan(M, N, K, dtype);
+  return p.sr > 1 ? (size_t)p.sr * M * (N - p.n1) * sizeof(float) : 0;
 }
 
 // mode: 0 = plain ring loop, 4 / 5 = software-pipelined loop over a 4- / 5-deep ring
@@ -468,6 +599,18 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
                           int out_dtype, int epilogue, int force_splits, int mode, hipStream_t st) {
   int splits = force_splits > 0 ? force_splits : fvqa_gemm_splits(M, N, K, dtype);
   const bool partial = epilogue == FVQA_EPI_PARTIAL;
+  if (!partial && force_splits == 0 && splits == 1 && tail == nullptr && ws != nullptr) {
+    const TailPlan p = tail_plan(M, N, K, dtype);
+    if (p.sr > 1 && ws_bytes >= (size_t)p.sr * M * (N - p.n1) * sizeof(float)) {
+      const size_t eo = out_dtype == FVQA_F32 ? 4 : fvqa_dtype_size(dtype), ei = fvqa_dtype_size(dtype);
+      int rc = fvqa_gemm_nt_256_impl(A, B, C, R, nullptr, ws, ws_bytes, M, p.n1, K, lda, ldb, ldc, m_split, dtype,
+                                     out_dtype, epilogue, 1, mode, st);
+      if (rc) return rc;
+      return fvqa_gemm_nt_256_impl(A, (const char*)B + (size_t)p.n1 * ldb * ei, (char*)C + (size_t)p.n1 * eo,
+                                   R ? (const char*)R + (size_t)p.n1 * ei : nullptr, nullptr, ws, ws_bytes, M,
+                                   N - p.n1, K, lda, ldb, ldc, m_split, dtype, out_dtype, epilogue, p.sr, mode, st);
+    }
+  }
   if (partial) {
     if (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3)) return FVQA_EALIGN;
   } else if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3))) {
@@ -481,6 +624,7 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
                                                    m_split, splits, partial, st)
 #define GO(T, TO)                     \
   if (mode == 2) { GO2(T, TO, 2); }   \
+  if (mode == 3) { GO2(T, TO, 3); }   \
   if (mode == 5) { GO2(T, TO, 5); }   \
   if (mode == 4) { GO2(T, TO, 4); }   \
   GO2(T, TO, 0)

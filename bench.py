@@ -11,7 +11,7 @@ batch 8 per GPU, max_feats 10, VQA loss only. N>1 = the same per-GPU work on eve
 scaling), one all-reduce(mean) of 4.5 M fp32 gradients per step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     — the dominant kernel (bf16 projection GEMM gemm_nt_128): algorithmic FLOPs per
+  roofline     — the dominant kernel (bf16 projection GEMM gemm_nt_256): algorithmic FLOPs per
                  launch / average launch time from HIP events around each launch in a separate
                  instrumented pass of the same steps, against the 2.5 PFLOP/s dense bf16 MFMA peak;
   step_roofline— algorithmic FLOPs of the whole step (SURVEY §8d formula) / step time;
@@ -171,7 +171,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss_val = float(loss.sum())
+    loss_val = float(loss.detach().sum())
     ms = dt / a.steps * 1e3
     value = a.batch_size * world * a.steps / dt
 
@@ -184,17 +184,35 @@ def main():
             one_step(i)
         torch.cuda.synchronize()
         ops.GEMM_TIMING = None
-        sel = [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, key) in rec if key == "bf16_bf16_none"] \
-            if a.dtype == "bf16" else [(e0.elapsed_time(e1) * 1e-3, fl) for (e0, e1, fl, key) in rec]
-        if sel:
-            tot_t = sum(s[0] for s in sel)
-            tot_f = sum(s[1] for s in sel)
-            n = len(sel)
+        # launches that are exactly one gemm_nt_256 kernel (no fix-up pass inside the event pair):
+        # "plain" = direct-store instantiation, "partial" = split-K partials consumed by a fused norm
+        want = ("bf16_bf16_none_plain", "bf16_bf16_none_partial") if a.dtype == "bf16" else \
+               ("f32_f32_none_plain", "f32_f32_none_partial")
+        per = {}
+        for (e0, e1, fl, key) in rec:
+            if key in want:
+                t_, f_, n_ = per.get(key, (0.0, 0.0, 0))
+                per[key] = (t_ + e0.elapsed_time(e1) * 1e-3, f_ + fl, n_ + 1)
+        if per:
+            tot_t = sum(v[0] for v in per.values())
+            tot_f = sum(v[1] for v in per.values())
+            n = sum(v[2] for v in per.values())
             peak = MFMA_BF16_PEAK if a.dtype == "bf16" else 157.3e12
-            roof = {"bound": "mfma", "kernel": "gemm_nt_128<bf16,bf16,glds,none>" if a.dtype == "bf16" else "gemm_nt_128<f32>",
+            traffic, tsrc = None, None
+            tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+            if a.dtype == "bf16" and a.model == "7B" and not (a.vaq or a.qav) and os.path.exists(tj):
+                pm = json.load(open(tj))                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+                w_ = [(v["launches_sampled"], v["hbm_bytes_per_launch"]) for k, v in pm.items() if "float," not in k]
+                traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
+                tsrc = "profiles/r01_pmc_gemm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, same workload)"
+            roof = {"bound": "mfma",
+                    "kernel": "gemm_nt_256<bf16,bf16,EPI_NONE,{plain|split-K partial},ring=3>" if a.dtype == "bf16" else "gemm_nt_256<f32>",
                     "achieved": tot_f / tot_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                    "frac": tot_f / tot_t / peak, "traffic": None, "launches_per_step": n // a.steps,
-                    "avg_launch_us": tot_t / n * 1e6, "avg_flops_per_launch": tot_f / n}
+                    "frac": tot_f / tot_t / peak, "traffic": traffic, "traffic_source": tsrc,
+                    "launches_per_step": n // a.steps, "avg_launch_us": tot_t / n * 1e6,
+                    "avg_flops_per_launch": tot_f / n,
+                    "per_instantiation": {k: {"launches_per_step": v[2] // a.steps, "avg_launch_us": v[0] / v[2] * 1e6,
+                                              "TFLOP/s": v[1] / v[0] / 1e12} for k, v in per.items()}}
 
     if rank == 0:
         tasks = ["vqa"] + (["vaq"] if a.vaq else []) + (["qav"] if a.qav else [])

@@ -108,7 +108,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
                           _stream())
     if timing is not None:
         e1.record()
-        key = f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_{'res' if epi else 'none'}"
+        key = f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_{'res' if epi else 'none'}_{'fix' if need else 'plain'}"
         timing.append((e0, e1, 2.0 * M * N * K, key))
     _lib.check(rc, "fvqa_gemm_nt")
     return out
@@ -135,7 +135,7 @@ def gemm_nt_partial(a: torch.Tensor, b: torch.Tensor):
                           _ptr(ws), ws.numel(), _stream())
     if timing is not None:
         e1.record()
-        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[a.dtype]}_none"))
+        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[a.dtype]}_none_partial"))
     _lib.check(rc, "fvqa_gemm_nt(partial)")
     return ws[:need].view(torch.float32).view(splits, M, N), splits
 

@@ -202,15 +202,26 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     FVQA_DSR(A_[0], pa_, 0);    FVQA_DSR(A_[1], pa_, 2048);  FVQA_DSR(A_[2], pa_, 4096);  FVQA_DSR(A_[3], pa_, 6144);  \
     FVQA_DSR(A_[4], pa_, 8192); FVQA_DSR(A_[5], pa_, 10240); FVQA_DSR(A_[6], pa_, 12288); FVQA_DSR(A_[7], pa_, 14336); \
   }
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 1)
+#define FVQA_WROW(i, n)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
+  asm volatile("" ::"v"(a[i]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));            \
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #define FVQA_WROW(i, n)                                                                \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
   Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
   Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
   __builtin_amdgcn_sched_barrier(0);
+#endif
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 2)
+#define FVQA_WROW_DMA(i, n, q) FVQA_WROW(i, n)
+#else
 #define FVQA_WROW_DMA(i, n, q)                                                         \
   FVQA_WROW(i, n)                                                                      \
   if (more) issue_piece(nu, nslot, q);                                                 \
   __builtin_amdgcn_sched_barrier(0);
+#endif
     // prologue: A stage 0; B stages 0 and 1
     if (nw > 0) {
 #pragma unroll
@@ -224,7 +235,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     for (int u = 0; u < nw; ++u) {
       if (bwave && u + 1 < nw) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // B(u) landed, B(u+1) in flight
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(FVQA_ABLATE) && (FVQA_ABLATE & 8))
       __builtin_amdgcn_s_barrier();                       // stage u published; slots of stage u-1 are free
+#endif
       asm volatile("" ::: "memory");
       // next DMA of this wave: A(u+1) -> A slot (u+1)%2, or B(u+2) -> B slot (u+2)%3
       const int nu = bwave ? u + 2 : u + 1;

@@ -97,10 +97,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    local = local % max(1, torch.cuda.device_count())       # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)
+        # RCCL over xGMI; FVQA_DIST_BACKEND=gloo only for single-GPU rehearsals of the N>1 control flow
+        dist.init_process_group(os.environ.get("FVQA_DIST_BACKEND", "nccl"), init_method="env://",
+                                world_size=world, rank=rank)
 
     import util.misc as misc
     from fvqa import ops, synth
@@ -177,13 +180,14 @@ def main():
 
     # ---- instrumented pass: HIP events around every launch of the dominant kernel
     roof = None
+    rec = []
     if rank == 0:
-        rec = []
         ops.GEMM_TIMING = rec
-        for i in range(a.steps):
-            one_step(i)
-        torch.cuda.synchronize()
-        ops.GEMM_TIMING = None
+    for i in range(a.steps):                 # every rank runs it: the step contains the gradient all-reduce
+        one_step(i)
+    fence()
+    ops.GEMM_TIMING = None
+    if rank == 0:
         # launches that are exactly one gemm_nt_256 kernel (no fix-up pass inside the event pair):
         # "plain" = direct-store instantiation, "partial" = split-K partials consumed by a fused norm
         want = ("bf16_bf16_none_plain", "bf16_bf16_none_partial") if a.dtype == "bf16" else \

@@ -160,28 +160,30 @@ __global__ __launch_bounds__(256) void sum_tail_k(const float* __restrict__ ws, 
 }
 
 // ---- RoPE on q,k of the fused qkv rows (reference llama/model.py:61-67) ---------------------
+// one 256-thread workgroup per row, 8 elements (4 rotation pairs, 16 B of bf16) per thread
 template <typename T>
 __global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const float* __restrict__ cs,
-                                                 const float* __restrict__ sn, int rows, int seq_len, int dim,
+                                                 const float* __restrict__ sn, int seq_len, int dim,
                                                  int head_dim, float sign) {
-  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x;
   const int pos = row % seq_len;
   const int hp = head_dim >> 1;
   T* base = qkv + (size_t)row * 3 * dim;
-  for (int c = lane * 4; c < 2 * dim; c += 256) {      // q block then k block are contiguous
-    const int d = (c % dim) % head_dim;                 // even, multiple of 4
-    const int i0 = d >> 1;
-    float v[4], o[4];
-    Vec4<T>::load(base + c, v);
-    const float c0 = cs[pos * hp + i0], s0 = sign * sn[pos * hp + i0];
-    const float c1 = cs[pos * hp + i0 + 1], s1 = sign * sn[pos * hp + i0 + 1];
-    o[0] = v[0] * c0 - v[1] * s0;
-    o[1] = v[0] * s0 + v[1] * c0;
-    o[2] = v[2] * c1 - v[3] * s1;
-    o[3] = v[2] * s1 + v[3] * c1;
-    Vec4<T>::store(base + c, o);
+  const float* cr = cs + (size_t)pos * hp;
+  const float* sr = sn + (size_t)pos * hp;
+  for (int c = threadIdx.x * 8; c < 2 * dim; c += 2048) {      // q block then k block are contiguous
+    const int i0 = ((c % dim) % head_dim) >> 1;                 // first of 4 consecutive pair indices
+    float v[8], o[8];
+    load8<T>(base + c, v);
+    const float4 c4 = *reinterpret_cast<const float4*>(cr + i0);
+    const float4 s4 = *reinterpret_cast<const float4*>(sr + i0);
+    const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x * sign, s4.y * sign, s4.z * sign, s4.w * sign};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      o[2 * p] = v[2 * p] * cc[p] - v[2 * p + 1] * ss[p];
+      o[2 * p + 1] = v[2 * p] * ss[p] + v[2 * p + 1] * cc[p];
+    }
+    store8<T>(base + c, o);
   }
 }
 
@@ -364,10 +366,10 @@ extern "C" int fvqa_rope_qk(void* qkv, const float* cos_t, const float* sin_t, i
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
   if (n_seq <= 0 || seq_len <= 0 || n_heads <= 0 || head_dim <= 0 || head_dim % 4) return FVQA_ESHAPE;
   const int rows = n_seq * seq_len, dim = n_heads * head_dim;
-  dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(256);
+  if (head_dim % 8) return FVQA_ESHAPE;
   const float sign = inverse ? -1.f : 1.f;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(rope_qk_k<T>, grid, block, 0, (hipStream_t)stream, (T*)qkv, cos_t, sin_t,
-                                       rows, seq_len, dim, head_dim, sign));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rope_qk_k<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (T*)qkv, cos_t,
+                                       sin_t, seq_len, dim, head_dim, sign));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }

@@ -1,0 +1,160 @@
+// Native layer schedule: the per-layer kernel sequence of the Flipped-VQA step walked in C++.
+//
+// The Python host (fvqa/step.py) can issue every kernel itself (~700 ctypes calls per step, used
+// for per-launch timing and debugging) or hand this file one plan per (n_seq, S) geometry and make
+// two calls per step: fvqa_layers_fwd / fvqa_layers_bwd. Same kernels, same order, same results
+// (tests/test_step_gpu.py checks bitwise equality of the two schedules); what changes is that the
+// launch stream no longer depends on the speed of the Python interpreter.
+//
+// Sequence per layer (reference llama/model.py:184-187 with Attention :87-128, FeedForward :141-142):
+//   fwd: [xn = RMSNorm(x)] -> adapter rows -> QKV GEMM -> RoPE -> attention -> WO GEMM (split-K
+//        partials) -> fused residual+RMSNorm -> W1|W3 GEMM -> SwiGLU -> W2 GEMM (partials) -> fused
+//        residual+RMSNorm of the NEXT layer (or the final norm)
+//   bwd: W2^T GEMM -> SwiGLU' -> W1|W3^T GEMM (partials) -> fused RMSNorm' (+residual grad) ->
+//        WO^T GEMM -> attention' -> RoPE^-1 -> QKV^T GEMM (partials, adapter-gradient tail rows) ->
+//        fused RMSNorm' (+residual grad)
+#include "common.h"
+
+extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p);
+
+namespace {
+
+inline char* at(void* base, size_t elems, size_t esize) { return (char*)base + elems * esize; }
+inline const char* at(const void* base, size_t elems, size_t esize) { return (const char*)base + elems * esize; }
+
+#define RUN(call)            \
+  do {                       \
+    int rc__ = (call);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+int check_plan_dims_only(const fvqa_layer_plan* p) {
+  if (!p) return FVQA_EINVAL;
+  if (!fvqa_dtype_ok(p->dtype)) return FVQA_EINVAL;
+  if (p->n_layers <= 0 || p->n_seq <= 0 || p->seq_len <= 0 || p->dim <= 0 || p->hidden <= 0) return FVQA_ESHAPE;
+  if (p->n_heads * p->head_dim != p->dim) return FVQA_ESHAPE;
+  return FVQA_OK;
+}
+
+int check_plan(const fvqa_layer_plan* p) {
+  int rc = check_plan_dims_only(p);
+  if (rc) return rc;
+  if (p->gemm_ws_bytes < fvqa_layers_gemm_workspace(p)) return FVQA_EALIGN;
+  if (!p->wqkv || !p->wo || !p->w13 || !p->w2 || !p->wqkv_t || !p->wo_t || !p->w13_t || !p->w2_t || !p->an ||
+      !p->fn || !p->gate1 || !p->gate2 || !p->adapter || !p->norm_w || !p->xs || !p->rstd1 || !p->rstd2 || !p->qkv ||
+      !p->o || !p->lse_a || !p->lse_t || !p->h || !p->ab || !p->xn || !p->hn || !p->z || !p->xnf || !p->rstdN ||
+      !p->cos_t || !p->sin_t || !p->vstart || !p->gemm_ws)
+    return FVQA_EINVAL;
+  return FVQA_OK;
+}
+
+}  // namespace
+
+extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p) {
+  if (check_plan_dims_only(p)) return 0;
+  const int dt = p->dtype, D = p->dim, Hf = p->hidden, R = p->n_seq * p->seq_len, Ra = R + p->adapter_len;
+  size_t need = 0;
+  auto upd = [&](size_t v) { if (v > need) need = v; };
+  auto part = [&](int M, int N, int K) { return (size_t)fvqa_gemm_splits(M, N, K, dt) * M * N * sizeof(float); };
+  upd(fvqa_gemm_workspace(Ra, 3 * D, D, dt));       // QKV
+  upd(part(R, D, D));                                // WO partials
+  upd(fvqa_gemm_workspace(R, 2 * Hf, D, dt));        // W1|W3
+  upd(part(R, D, Hf));                               // W2 partials
+  upd(fvqa_gemm_workspace(R, Hf, D, dt));            // W2^T
+  upd(part(R, D, 2 * Hf));                           // W1|W3^T partials
+  upd(fvqa_gemm_workspace(R, D, D, dt));             // WO^T
+  upd(part(Ra, D, 3 * D));                           // QKV^T partials
+  return need;
+}
+
+extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
+  RUN(check_plan(p));
+  const int dt = p->dtype, L = p->n_layers, D = p->dim, Hf = p->hidden, H = p->n_heads, Dh = p->head_dim;
+  const int A = p->adapter_len, S = p->seq_len, n_seq = p->n_seq;
+  const int R = n_seq * S, Ra = R + A;
+  const size_t es = fvqa_dtype_size(dt);
+  char* xn_tail = at(p->xn, (size_t)R * D, es);
+  RUN(fvqa_rmsnorm_fwd(p->xs, p->an[0], p->xn, p->rstd1, R, D, p->eps, dt, stream));
+  for (int i = 0; i < L; ++i) {
+    const void* x = at(p->xs, (size_t)i * R * D, es);
+    void* x_next = at(p->xs, (size_t)(i + 1) * R * D, es);
+    void* qkv = at(p->qkv, (size_t)i * Ra * 3 * D, es);
+    void* o = at(p->o, (size_t)i * R * D, es);
+    void* h = at(p->h, (size_t)i * R * D, es);
+    void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
+    float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
+    float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
+    RUN(fvqa_cast_rows(p->adapter + (size_t)i * A * D, xn_tail, A, D, dt, stream));
+    RUN(fvqa_gemm_nt(p->xn, p->wqkv[i], qkv, nullptr, nullptr, Ra, 3 * D, D, D, D, 3 * D, Ra, dt, dt, FVQA_EPI_NONE, 0,
+                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_rope_qk(qkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 0, dt, stream));
+    RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, n_seq, S, H, Dh, A, p->max_feats, dt,
+                      stream));
+    // WO: split-K partials summed by the fused residual + ffn-norm kernel
+    int sp = fvqa_gemm_splits(R, D, D, dt);
+    RUN(fvqa_gemm_nt(o, p->wo[i], nullptr, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_PARTIAL, 0,
+                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, x, p->fn[i], h, p->hn,
+                                p->rstd2 + (size_t)i * R, R, D, p->eps, dt, stream));
+    RUN(fvqa_gemm_nt(p->hn, p->w13[i], ab, nullptr, nullptr, R, 2 * Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_NONE, 0,
+                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_swiglu_fwd(ab, p->z, R, Hf, dt, stream));
+    sp = fvqa_gemm_splits(R, D, Hf, dt);
+    RUN(fvqa_gemm_nt(p->z, p->w2[i], nullptr, nullptr, nullptr, R, D, Hf, Hf, Hf, D, R, dt, dt, FVQA_EPI_PARTIAL, 0,
+                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    if (i + 1 < L) {
+      RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->an[i + 1], x_next, p->xn,
+                                  p->rstd1 + (size_t)(i + 1) * R, R, D, p->eps, dt, stream));
+    } else {
+      RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->norm_w, x_next, p->xnf, p->rstdN,
+                                  R, D, p->eps, dt, stream));
+    }
+  }
+  return FVQA_OK;
+}
+
+// dxnf: gradient w.r.t. the final-norm output (R, D). On return *d_x0 points at the gradient w.r.t.
+// the layer-0 input (one of the plan's two ping-pong buffers).
+extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void** d_x0, void* stream) {
+  RUN(check_plan(p));
+  if (!dxnf || !d_x0 || !p->dcur || !p->dnxt || !p->dz || !p->dab || !p->dh || !p->d_o || !p->dqkv || !p->attn_ws ||
+      !p->dgate1 || !p->dgate2 || !p->d_adapter)
+    return FVQA_EINVAL;
+  const int dt = p->dtype, L = p->n_layers, D = p->dim, Hf = p->hidden, H = p->n_heads, Dh = p->head_dim;
+  const int A = p->adapter_len, S = p->seq_len, n_seq = p->n_seq;
+  const int R = n_seq * S, Ra = R + A;
+  const size_t es = fvqa_dtype_size(dt);
+  void* cur = p->dcur;
+  void* nxt = p->dnxt;
+  RUN(fvqa_rmsnorm_bwd(dxnf, at(p->xs, (size_t)L * R * D, es), p->norm_w, p->rstdN, nullptr, cur, R, D, dt, stream));
+  for (int i = L - 1; i >= 0; --i) {
+    const void* x = at(p->xs, (size_t)i * R * D, es);
+    const void* qkv = at(p->qkv, (size_t)i * Ra * 3 * D, es);
+    const void* o = at(p->o, (size_t)i * R * D, es);
+    const void* h = at(p->h, (size_t)i * R * D, es);
+    const void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
+    const float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
+    const float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
+    RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dz, nullptr, nullptr, R, Hf, D, D, D, Hf, R, dt, dt, FVQA_EPI_NONE, 0,
+                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_swiglu_bwd(p->dz, ab, p->dab, R, Hf, dt, stream));
+    int sp = fvqa_gemm_splits(R, D, 2 * Hf, dt);
+    RUN(fvqa_gemm_nt(p->dab, p->w13_t[i], nullptr, nullptr, nullptr, R, D, 2 * Hf, 2 * Hf, 2 * Hf, D, R, dt, dt,
+                     FVQA_EPI_PARTIAL, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_sum_rmsnorm_bwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->fn[i], p->rstd2 + (size_t)i * R, cur,
+                             p->dh, nullptr, 0, R, D, dt, stream));
+    RUN(fvqa_gemm_nt(p->dh, p->wo_t[i], p->d_o, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_NONE, 0,
+                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_attn_bwd(p->d_o, qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->dqkv, p->dgate1[i],
+                      p->dgate2[i], p->attn_ws, p->attn_ws_bytes, n_seq, S, H, Dh, A, p->max_feats, dt, stream));
+    RUN(fvqa_rope_qk(p->dqkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 1, dt, stream));
+    sp = fvqa_gemm_splits(Ra, D, 3 * D, dt);
+    RUN(fvqa_gemm_nt(p->dqkv, p->wqkv_t[i], nullptr, nullptr, nullptr, Ra, D, 3 * D, 3 * D, 3 * D, D, Ra, dt, dt,
+                     FVQA_EPI_PARTIAL, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_sum_rmsnorm_bwd((const float*)p->gemm_ws, sp, (size_t)Ra * D, x, p->an[i], p->rstd1 + (size_t)i * R,
+                             p->dh, nxt, p->d_adapter + (size_t)i * A * D, A, R, D, dt, stream));
+    void* t = cur; cur = nxt; nxt = t;
+  }
+  *d_x0 = cur;
+  return FVQA_OK;
+}

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -46,7 +46,28 @@ SIGNATURES = {
     "fvqa_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p]),
     "fvqa_scaler_update": (_i, [_p, _p, _p, _p, _f, _f, _i, _p]),
     "fvqa_cast_rows": (_i, [_p, _p, _i, _i, _i, _p]),
+    "fvqa_layers_gemm_workspace": (_sz, [_p]),
+    "fvqa_layers_fwd": (_i, [_p, _p]),
+    "fvqa_layers_bwd": (_i, [_p, _p, _p, _p]),
 }
+
+_pp = C.POINTER(C.c_void_p)
+
+
+class LayerPlan(C.Structure):
+    """Mirror of `fvqa_layer_plan` (include/fvqa.h) — field order and types must match exactly."""
+    _fields_ = (
+        [(n, C.c_int32) for n in ("dtype", "n_layers", "n_seq", "seq_len", "n_heads", "head_dim", "adapter_len",
+                                  "max_feats", "dim", "hidden")]
+        + [("eps", C.c_float), ("reserved_", C.c_int32)]
+        + [(n, _pp) for n in ("wqkv", "wo", "w13", "w2", "wqkv_t", "wo_t", "w13_t", "w2_t", "an", "fn", "gate1",
+                              "gate2", "dgate1", "dgate2")]
+        + [(n, C.c_void_p) for n in ("adapter", "d_adapter", "norm_w", "xs", "rstd1", "rstd2", "qkv", "o", "lse_a",
+                                     "lse_t", "h", "ab", "xn", "hn", "z", "xnf", "rstdN", "cos_t", "sin_t",
+                                     "vstart", "dcur", "dnxt", "dz", "dab", "dh", "d_o", "dqkv", "attn_ws")]
+        + [("attn_ws_bytes", C.c_size_t), ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t)]
+    )
+
 
 ERRORS = {-1: "FVQA_EINVAL (null pointer / bad enum)", -2: "FVQA_ESHAPE (unsupported dimension)",
           -3: "FVQA_EALIGN (misaligned pointer / short workspace)"}

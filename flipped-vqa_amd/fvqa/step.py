@@ -15,11 +15,13 @@ Design (MI355X-first, not a port of the reference's autograd graph):
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 
 TASKS = ("vqa", "vaq", "qav")
 
@@ -149,6 +151,53 @@ class StepEngine:
         self.saved = None
         self.keep_logits = False
 
+    # ------------------------------------------------------------------ native layer schedule
+    def layer_plan(self, ar: "Arena", grads: "FlatParams", vstart: torch.Tensor):
+        """fvqa_layer_plan for this arena (built once, cached on the arena; csrc/schedule.hip walks it)."""
+        key = (vstart.data_ptr(), grads.flat_grad.data_ptr())
+        if getattr(ar, "_plan_key", None) == key:
+            return ar._plan
+        m, pk, L = self.model, self.pack, self.L
+        plan = _lib.LayerPlan()
+        for k, v in dict(dtype=ops.dt_code(self.dtype), n_layers=L, n_seq=ar.n_seq, seq_len=ar.S, n_heads=self.H,
+                         head_dim=self.Dh, adapter_len=self.A, max_feats=self.F, dim=self.D, hidden=self.Hf).items():
+            setattr(plan, k, v)
+        plan.eps = float(self.eps)
+        keep = []
+
+        def table(tensors):
+            arr = (C.c_void_p * L)(*[t.data_ptr() for t in tensors])
+            keep.append((arr, tensors))
+            return C.cast(arr, C.POINTER(C.c_void_p))
+
+        for name in ("wqkv", "wo", "w13", "w2", "wqkv_t", "wo_t", "w13_t", "w2_t", "an", "fn"):
+            setattr(plan, name, table(getattr(pk, name)))
+        gv = [m.gate_views(i) for i in range(L)]
+        gg = [grads.gate_grad_views(i) for i in range(L)]
+        plan.gate1, plan.gate2 = table([g[0] for g in gv]), table([g[1] for g in gv])
+        plan.dgate1, plan.dgate2 = table([g[0] for g in gg]), table([g[1] for g in gg])
+        plan.adapter = m.adapter_query.weight.data.data_ptr()
+        plan.d_adapter = grads.grad_view("adapter_query.weight").data_ptr()
+        plan.norm_w = pk.norm.data_ptr()
+        for name in ("xs", "rstd1", "rstd2", "qkv", "o", "lse_a", "lse_t", "h", "ab", "xn", "hn", "z", "xnf", "rstdN",
+                     "dz", "dab", "dh", "dqkv", "attn_ws"):
+            setattr(plan, name, getattr(ar, name).data_ptr())
+        plan.dcur, plan.dnxt, plan.d_o = ar.da.data_ptr(), ar.db.data_ptr(), ar.do.data_ptr()
+        plan.cos_t, plan.sin_t, plan.vstart = self.cos.data_ptr(), self.sin.data_ptr(), vstart.data_ptr()
+        plan.attn_ws_bytes = ar.attn_ws.numel()
+        lib = _lib.load()
+        need = int(lib.fvqa_layers_gemm_workspace(C.addressof(plan)))
+        if getattr(ar, "plan_ws", None) is None or ar.plan_ws.numel() < need:
+            ar.plan_ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        plan.gemm_ws, plan.gemm_ws_bytes = ar.plan_ws.data_ptr(), ar.plan_ws.numel()
+        ar._plan, ar._plan_keep, ar._plan_key = plan, keep, key
+        return plan
+
+    @staticmethod
+    def use_native_schedule() -> bool:
+        # the per-kernel Python schedule stays for per-launch timing (bench.py) and debugging
+        return os.environ.get("FVQA_PY_SCHEDULE") != "1" and ops.GEMM_TIMING is None
+
     # ------------------------------------------------------------------ helpers
     def arena(self, n_seq, S) -> Arena:
         key = (n_seq, S)
@@ -213,6 +262,32 @@ class StepEngine:
             else:
                 ops.embed_splice(ids[t], pk.emb, vf_tok, h0, B, S, F, vstart=vs[t], mode=0)
 
+        if self.use_native_schedule():
+            plan = self.layer_plan(ar, m._flat, vstart)
+            _lib.check(_lib.load().fvqa_layers_fwd(C.addressof(plan), torch.cuda.current_stream().cuda_stream),
+                       "fvqa_layers_fwd")
+        else:
+            self._layers_fwd_py(ar, vstart, n_seq, S)
+        n_lm = ar.n_lm
+        ops.gemm_nt(ar.xnf[: n_lm * S], pk.wout, ar.logits)
+        ar.loss_sum.zero_()
+        for k, t in enumerate(self.tasks):
+            rows = slice(k * B * S, (k + 1) * B * S)
+            if t == "qav":
+                ops.qav_head_fwd(ar.xnf[rows], vf_raw, labels[t], ar.probs[k * B * S * F:], ar.rowloss[rows],
+                                 ar.loss_sum[2], B, S, D, F, self.tau)
+            else:
+                ops.ce_fwd(ar.logits[rows], labels[t], ar.lse[rows], ar.rowloss[rows], ar.loss_sum[k], B, S, V, 0)
+        self.saved = dict(ar=ar, B=B, S=S, vs=vs, labels=labels, qidx=qidx, video=video_d, vf_raw=vf_raw,
+                          vstart=vstart)
+        losses = ar.loss_sum[:, 0] / ar.loss_sum[:, 1]        # mean over scored rows (NaN if none, as torch CE)
+        return losses
+
+    def _layers_fwd_py(self, ar, vstart, n_seq, S):
+        """The same layer walk as csrc/schedule.hip, one ctypes call per kernel."""
+        m, pk = self.model, self.pack
+        F, D, A, H, Dh, Hf, L = self.F, self.D, self.A, self.H, self.Dh, self.Hf, self.L
+        R, Ra = ar.R, ar.Ra
         adapter = m.adapter_query.weight.data.view(-1, A, D)     # (adapter_layer, A, D); model.py:304
         # WO and W2 have N = D outputs (few tiles): their GEMMs leave fp32 split-K partials and the
         # following "residual add + RMSNorm" kernel sums them (no separate fix-up pass, no extra
@@ -234,20 +309,6 @@ class StepEngine:
                 ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.an[i + 1], ar.xs[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, R)
             else:
                 ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.norm, ar.xs[L], ar.xnf, ar.rstdN, self.eps, R)
-        n_lm = ar.n_lm
-        ops.gemm_nt(ar.xnf[: n_lm * S], pk.wout, ar.logits)
-        ar.loss_sum.zero_()
-        for k, t in enumerate(self.tasks):
-            rows = slice(k * B * S, (k + 1) * B * S)
-            if t == "qav":
-                ops.qav_head_fwd(ar.xnf[rows], vf_raw, labels[t], ar.probs[k * B * S * F:], ar.rowloss[rows],
-                                 ar.loss_sum[2], B, S, D, F, self.tau)
-            else:
-                ops.ce_fwd(ar.logits[rows], labels[t], ar.lse[rows], ar.rowloss[rows], ar.loss_sum[k], B, S, V, 0)
-        self.saved = dict(ar=ar, B=B, S=S, vs=vs, labels=labels, qidx=qidx, video=video_d, vf_raw=vf_raw,
-                          vstart=vstart)
-        losses = ar.loss_sum[:, 0] / ar.loss_sum[:, 1]        # mean over scored rows (NaN if none, as torch CE)
-        return losses
 
     # ------------------------------------------------------------------ backward
     def backward(self, g_losses: torch.Tensor, grads: "FlatParams"):
@@ -274,6 +335,29 @@ class StepEngine:
                 ops.ce_bwd(ar.logits[rows], labels[t], ar.lse[rows], ar.loss_sum[k], ar.gscale[k:k + 1],
                            ar.dlogits[rows], B, S, V, 0)
         ops.gemm_nt(ar.dlogits, pk.wout_t, ar.dxnf[: ar.n_lm * S])
+        if self.use_native_schedule():
+            plan = self.layer_plan(ar, grads, sv["vstart"])
+            out = C.c_void_p()
+            _lib.check(_lib.load().fvqa_layers_bwd(C.addressof(plan), ar.dxnf.data_ptr(), C.addressof(out),
+                                                   torch.cuda.current_stream().cuda_stream), "fvqa_layers_bwd")
+            cur = ar.da if out.value == ar.da.data_ptr() else ar.db
+        else:
+            cur = self._layers_bwd_py(ar, grads, sv, n_seq, S)
+        for k, t in enumerate(self.tasks):
+            dh0 = cur[k * B * S:(k + 1) * B * S]
+            if t == "qav":
+                ops.splice_bwd(dh0, ar.d_tok, B, S, F, index=sv["qidx"], mode=1)
+            else:
+                ops.splice_bwd(dh0, ar.d_tok, B, S, F, vstart=vs[t], mode=0)
+        ops.visual_proj_bwd(ar.d_tok, ar.d_qav if has_qav else None, sv["video"],
+                            grads.grad_view("visual_proj.weight"), grads.grad_view("temporal_emb.weight"))
+        self.saved = None
+
+
+    def _layers_bwd_py(self, ar, grads, sv, n_seq, S):
+        m, pk = self.model, self.pack
+        F, D, A, H, Dh, Hf, L = self.F, self.D, self.A, self.H, self.Dh, self.Hf, self.L
+        R, Ra = ar.R, ar.Ra
         cur, nxt = ar.da, ar.db
         ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
         g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
@@ -291,15 +375,7 @@ class StepEngine:
             ws, _ = ops.gemm_nt_partial(ar.dqkv, pk.wqkv_t[i])
             ops.sum_rmsnorm_bwd(ws, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, R, resid=ar.dh, tail=g_adapter[i])
             cur, nxt = nxt, cur
-        for k, t in enumerate(self.tasks):
-            dh0 = cur[k * B * S:(k + 1) * B * S]
-            if t == "qav":
-                ops.splice_bwd(dh0, ar.d_tok, B, S, F, index=sv["qidx"], mode=1)
-            else:
-                ops.splice_bwd(dh0, ar.d_tok, B, S, F, vstart=vs[t], mode=0)
-        ops.visual_proj_bwd(ar.d_tok, ar.d_qav if has_qav else None, sv["video"],
-                            grads.grad_view("visual_proj.weight"), grads.grad_view("temporal_emb.weight"))
-        self.saved = None
+        return cur
 
 
 class FlatParams:

@@ -188,6 +188,73 @@ int fvqa_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
 int fvqa_scaler_update(float* step, float* scale, float* growth_tracker, const float* found_inf,
                        float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
+/* ---- native layer schedule (csrc/schedule.hip): the L transformer blocks of the step walked in
+ * C++ — two calls per step instead of ~700 per-kernel calls from the host language. Every pointer
+ * is a device pointer except the per-layer tables (host arrays of n_layers device pointers).
+ * Layer-strided activation buffers are contiguous (layer-major) with R = n_seq*seq_len rows and
+ * Ra = R + adapter_len rows. */
+typedef struct fvqa_layer_plan {
+  int32_t dtype, n_layers, n_seq, seq_len, n_heads, head_dim, adapter_len, max_feats, dim, hidden;
+  float eps;
+  int32_t reserved_;
+  /* frozen weights, per layer: fused and transposed copies (storage dtype) */
+  const void* const* wqkv;   /* (3D, D)  */
+  const void* const* wo;     /* (D, D)   */
+  const void* const* w13;    /* (2Hf, D) */
+  const void* const* w2;     /* (D, Hf)  */
+  const void* const* wqkv_t; /* (D, 3D)  */
+  const void* const* wo_t;   /* (D, D)   */
+  const void* const* w13_t;  /* (D, 2Hf) */
+  const void* const* w2_t;   /* (Hf, D)  */
+  const void* const* an;     /* attention_norm weight (D) */
+  const void* const* fn;     /* ffn_norm weight (D)       */
+  const float* const* gate1; /* (H) fp32 */
+  const float* const* gate2;
+  float* const* dgate1;      /* (H) fp32, accumulated */
+  float* const* dgate2;
+  const float* adapter;      /* (L, A, D) fp32 adapter queries of the walked layers */
+  float* d_adapter;          /* (L, A, D) fp32, accumulated */
+  const void* norm_w;        /* final norm weight (D) */
+  /* forward arena */
+  void* xs;                  /* (L+1, R, D): xs[0] in, xs[L] out      */
+  float* rstd1;              /* (L, R) */
+  float* rstd2;              /* (L, R) */
+  void* qkv;                 /* (L, Ra, 3D) */
+  void* o;                   /* (L, R, D)   */
+  float* lse_a;              /* (L, n_seq*H*S) */
+  float* lse_t;
+  void* h;                   /* (L, R, D)   */
+  void* ab;                  /* (L, R, 2Hf) */
+  void* xn;                  /* (Ra, D) scratch */
+  void* hn;                  /* (R, D)  scratch */
+  void* z;                   /* (R, Hf) scratch */
+  void* xnf;                 /* (R, D) final-norm output */
+  float* rstdN;              /* (R) */
+  const float* cos_t;        /* (>=S, Dh/2) */
+  const float* sin_t;
+  const int32_t* vstart;     /* (n_seq) */
+  /* backward scratch */
+  void* dcur;                /* (R, D) */
+  void* dnxt;                /* (R, D) */
+  void* dz;                  /* (R, Hf) */
+  void* dab;                 /* (R, 2Hf) */
+  void* dh;                  /* (R, D) */
+  void* d_o;                 /* (R, D) */
+  void* dqkv;                /* (Ra, 3D) */
+  void* attn_ws;
+  size_t attn_ws_bytes;
+  void* gemm_ws;             /* >= fvqa_layers_gemm_workspace(plan) bytes */
+  size_t gemm_ws_bytes;
+} fvqa_layer_plan;
+
+/* bytes of split-K workspace the GEMMs of one layer (forward and backward) need at most */
+size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* plan);
+/* xs[0] -> ... -> xs[L], xnf = final RMSNorm; saves what the backward needs in the arena */
+int fvqa_layers_fwd(const fvqa_layer_plan* plan, void* stream);
+/* dxnf (R, D): gradient w.r.t. xnf. *d_x0 <- device pointer (plan->dcur or plan->dnxt) holding the
+ * gradient w.r.t. xs[0]; gate / adapter gradients are accumulated into the plan's buffers. */
+int fvqa_layers_bwd(const fvqa_layer_plan* plan, const void* dxnf, void** d_x0, void* stream);
+
 /* ---- small utilities -------------------------------------------------------------------
  * dst rows [row0, row0+n_rows) of a (.., dim) storage-dtype matrix <- fp32 src (n_rows, dim)
  * (adapter_query rows appended under the normed activations, llama/model.py:339) */

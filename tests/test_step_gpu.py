@@ -100,6 +100,24 @@ def test_autograd_grad_mode_equals_flat_mode():
             assert torch.equal(p.grad.float().cpu(), g_flat[n]), n
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_native_schedule_equals_python_schedule(dtype, monkeypatch):
+    """csrc/schedule.hip (two calls per step) and the per-kernel Python schedule launch the same
+    kernels in the same order: bitwise-equal losses, logits and gradients."""
+    cfg = synth.preset("small", vaq=True, qav=True)
+    model, _ = build_model(cfg, dtype)
+    batch = synth.make_batch(cfg, seed=6)
+    monkeypatch.delenv("FVQA_PY_SCHEDULE", raising=False)
+    l_nat, g_nat, lg_nat, _ = run_step(model, batch)
+    monkeypatch.setenv("FVQA_PY_SCHEDULE", "1")
+    l_py, g_py, lg_py, _ = run_step(model, batch)
+    assert l_nat == l_py
+    for t in lg_nat:
+        assert torch.equal(lg_nat[t], lg_py[t]), t
+    for n in g_nat:
+        assert torch.equal(g_nat[n], g_py[n]), n
+
+
 def test_step_is_bitwise_repeatable():
     """Same inputs twice -> bitwise equal losses and gradients (no atomics anywhere): the cheap
     race detector SURVEY §5 asks for."""

@@ -145,6 +145,28 @@ def test_ragged_long_sequence_properties():
         assert float((grads[n].double() - g).norm()) <= 1e-3 * float(g.norm()) + 1e-12, n
 
 
+def test_bf16_ragged_sequence_and_13b_head_count():
+    """bf16 build at a ragged S (MFMA attention tiles cut by the sequence end) and at 40 heads x 128
+    (the 13B head geometry at reduced depth): losses/gradients against the oracle."""
+    for over in (dict(max_seq_len=200, batch_size=1), dict(dim=640, n_heads=5, max_seq_len=72, batch_size=2)):
+        cfg = synth.preset("tiny", vaq=True, qav=True, **over)
+        model, _ = build_model(cfg, torch.bfloat16)
+        batch = synth.make_batch(cfg, seed=8)
+        losses, grads, _, _ = run_step(model, batch)
+        sd = synth.state_dict(cfg)
+        for n in sd:
+            if not synth.is_trainable(n):
+                sd[n] = sd[n].to(torch.bfloat16).float()
+        ref = _oracle(cfg, sd, batch)
+        for t in ref["tasks"]:
+            r = float(ref["losses"][t])
+            assert abs(losses[t] - r) / abs(r) < BF16_LOSS_RTOL, (over, t, losses[t], r)
+        for n, g in ref["grads"].items():
+            gn = float(g.norm())
+            if gn > 0:
+                assert float((grads[n].double() - g).norm()) / gn < BF16_GRAD_RTOL, (over, n)
+
+
 def test_forward_rejects_bad_inputs():
     cfg = synth.preset("tiny", vaq=True, qav=True)
     model, _ = build_model(cfg, torch.float32)

@@ -19,6 +19,7 @@
 // tile; its key/value gradients are summed over sequences by attn_bwd_reduce_k (attn.hip), exactly
 // as in the vector build: no float atomics, bitwise repeatable.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -75,11 +76,35 @@ __device__ __forceinline__ void stage_rows_t(bf16_t* sT, int ldt, const bf16_t* 
 __device__ __forceinline__ uint4 frag(const bf16_t* s, int ld, int row0, int k0, int lane) {
   return *reinterpret_cast<const uint4*>(s + (row0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
 }
+// B fragments taken COLUMN-wise from a row-major LDS tile X[k][n] with the hardware transpose read
+// ds_read_b64_tr_b16: per 16-lane group it reads 4 rows x 16 columns and hands lane i column i (its 4
+// rows in the 4 elements); lane 4q+p of the group supplies the address of row q, columns 4p..4p+3.
+// Two reads (rows 8g..8g+3 and 8g+4..8g+7 of the 32-deep k-step, g = lane>>4) make the 8-element
+// fragment B[k = 8g + j][n = n0 + (lane&15)]. Fills f[d] for the 8 column tiles n0 = 16*d; one wait.
+__device__ __forceinline__ void frags_tr8(const bf16_t* s, int k0, int lane, uint4 (&f)[8]) {
+  const int g = lane >> 4, i = lane & 15;
+  const bf16_t* a0 = s + (k0 + 8 * g + (i >> 2)) * LDR + 4 * (i & 3);
+  const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) bf16_t*)a0;
+  uint2 lo[8], hi[8];
+#define FVQA_TR(d)                                                                                       \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[d]) : "v"(addr), "i"(32 * d));            \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d]) : "v"(addr), "i"(32 * d + 8 * LDR));
+  FVQA_TR(0) FVQA_TR(1) FVQA_TR(2) FVQA_TR(3) FVQA_TR(4) FVQA_TR(5) FVQA_TR(6) FVQA_TR(7)
+#undef FVQA_TR
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                 "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+#pragma unroll
+  for (int d = 0; d < 8; ++d) f[d] = make_uint4(lo[d].x, lo[d].y, hi[d].x, hi[d].y);
+}
+
 __device__ __forceinline__ uint4 frag_g(const bf16_t* g, size_t ld, int row, int k0, int lane) {
   return *reinterpret_cast<const uint4*>(g + (size_t)row * ld + k0 + 8 * (lane >> 4));
 }
 
 // ------------------------------------------------------------------------------- forward
+// TR: take the V fragments with transposing LDS reads from the row-major tile (no transposed staging)
+template <bool TR>
 __global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                        float* __restrict__ lse_a, float* __restrict__ lse_t,
                                                        const float* __restrict__ gate1,
@@ -88,8 +113,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict_
                                                        int A, int F) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]
-  bf16_t* sVT = sK + KT * LDR;                            // [DH][LDT]
-  bf16_t* sP = sVT + DH * LDT;                            // [4][16][LDP]
+  bf16_t* sVT = sK + KT * LDR;                            // [DH][LDT]  (TR: [KT][LDR] row-major V)
+  bf16_t* sP = sVT + (TR ? KT * LDR : DH * LDT);          // [4][16][LDP]
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int D = H * DH;
@@ -119,7 +144,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict_
   for (int kt = 0; kt <= qb; ++kt) {
     __syncthreads();
     stage_rows(sK, seq + D, ld, kt * KT, S, KT);
-    stage_rows_t(sVT, LDT, seq + 2 * D, ld, kt * KT, S, KT);
+    if (TR) stage_rows(sVT, seq + 2 * D, ld, kt * KT, S, KT);
+    else stage_rows_t(sVT, LDT, seq + 2 * D, ld, kt * KT, S, KT);
     __syncthreads();
     f32x4 s[4];
 #pragma unroll
@@ -163,8 +189,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict_
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
       const uint4 pf = frag(myP, LDP, 0, 32 * k2, lane);
+      if (TR) {
+        uint4 vf8[8];
+        frags_tr8(sVT, 32 * k2, lane, vf8);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, frag(sVT, LDT, 16 * d, 32 * k2, lane), oacc[d]);
+        for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, vf8[d], oacc[d]);
+      } else {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, frag(sVT, LDT, 16 * d, 32 * k2, lane), oacc[d]);
+      }
     }
   }
   float lt[4];
@@ -181,7 +214,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict_
   const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
   __syncthreads();
   stage_rows(sK, arow + D, ld, 0, A, 16);
-  stage_rows_t(sVT, LDT, arow + 2 * D, ld, 0, A, 32);
+  if (TR) stage_rows(sVT, arow + 2 * D, ld, 0, A, 32);
+  else stage_rows_t(sVT, LDT, arow + 2 * D, ld, 0, A, 32);
   __syncthreads();
   f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -201,8 +235,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict_
   __syncthreads();
   {
     const uint4 pf = frag(myP, LDP, 0, 0, lane);
+    if (TR) {
+      uint4 vf8[8];
+      frags_tr8(sVT, 0, lane, vf8);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, frag(sVT, LDT, 16 * d, 0, lane), oacc[d]);
+      for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, vf8[d], oacc[d]);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, frag(sVT, LDT, 16 * d, 0, lane), oacc[d]);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -227,10 +268,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_k(
     float* __restrict__ delta_a, float* __restrict__ delta_t, float* __restrict__ gate_part, int n_seq, int S, int H,
     int A, int F) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]   K rows
+  bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]   K rows (also read column-wise for dS·K)
   bf16_t* sV = sK + KT * LDR;                             // [KT][LDR]   V rows
-  bf16_t* sKT = sV + KT * LDR;                            // [DH][LDT]   K transposed
-  bf16_t* sP = sKT + DH * LDT;                            // [4][16][LDP] dS tile per wave
+  bf16_t* sP = sV + KT * LDR;                             // [4][16][LDP] dS tile per wave
   __shared__ float red[8];
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -288,9 +328,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_k(
 
   // ---- adapter tile: dS_a, delta_a, d tanh-gate partial
   const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
-  stage_rows(sK, arow + D, ld, 0, A, 16);
+  stage_rows(sK, arow + D, ld, 0, A, 32);                 // rows >= A are zero (32 = one MFMA k-step)
   stage_rows(sV, arow + 2 * D, ld, 0, A, 16);
-  stage_rows_t(sKT, LDT, arow + D, ld, 0, A, 32);
   __syncthreads();
   float da[4], dg1 = 0.f;
   {
@@ -315,8 +354,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_k(
   __syncthreads();
   {
     const uint4 pf = frag(myP, LDP, 0, 0, lane);
+    uint4 kf8[8];
+    frags_tr8(sK, 0, lane, kf8);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) dq[d] = mma(pf, frag(sKT, LDT, 16 * d, 0, lane), dq[d]);
+    for (int d = 0; d < 8; ++d) dq[d] = mma(pf, kf8[d], dq[d]);
   }
   float dt[4], dg2 = 0.f;
 #pragma unroll
@@ -326,7 +367,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_k(
     __syncthreads();
     stage_rows(sK, seq + D, ld, kt * KT, S, KT);
     stage_rows(sV, seq + 2 * D, ld, kt * KT, S, KT);
-    stage_rows_t(sKT, LDT, seq + D, ld, kt * KT, S, KT);
     __syncthreads();
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -353,8 +393,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_k(
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
       const uint4 pf = frag(myP, LDP, 0, 32 * k2, lane);
+      uint4 kf8[8];
+      frags_tr8(sK, 32 * k2, lane, kf8);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) dq[d] = mma(pf, frag(sKT, LDT, 16 * d, 32 * k2, lane), dq[d]);
+      for (int d = 0; d < 8; ++d) dq[d] = mma(pf, kf8[d], dq[d]);
     }
   }
 #pragma unroll
@@ -389,11 +431,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_k(
     bf16_t* __restrict__ dqkv, float* __restrict__ dka_part, float* __restrict__ dva_part, int n_seq, int S, int H,
     int A, int F, int nkb) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]  Q rows
-  bf16_t* sdO = sQ + KT * LDR;                            // [KT][LDR]  dO rows
-  bf16_t* sQT = sdO + KT * LDR;                           // [DH][LDT]  Q transposed
-  bf16_t* sdOT = sQT + DH * LDT;                          // [DH][LDT]  dO transposed
-  bf16_t* sP = sdOT + DH * LDT;                           // [4][2][16][LDP]  P^T and dS^T per wave
+  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]  Q rows  (row reads for S^T, column reads for dK)
+  bf16_t* sdO = sQ + KT * LDR;                            // [KT][LDR]  dO rows (row reads for dP^T, column reads for dV)
+  bf16_t* sP = sdO + KT * LDR;                            // [4][2][16][LDP]  P^T and dS^T per wave
   float* sL = reinterpret_cast<float*>(sP + 4 * 2 * 16 * LDP);   // [KT] lse, [KT] delta
   float* sDl = sL + KT;
   const int kb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
@@ -437,8 +477,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_k(
     __syncthreads();
     stage_rows(sQ, seq, ld, t * KT, S, KT);
     stage_rows(sdO, dob, (size_t)D, t * KT, S, KT);
-    stage_rows_t(sQT, LDT, seq, ld, t * KT, S, KT);
-    stage_rows_t(sdOT, LDT, dob, (size_t)D, t * KT, S, KT);
     if (threadIdx.x < KT) {
       const int ii = min(t * KT + (int)threadIdx.x, S - 1);
       sL[threadIdx.x] = adapter ? lse_a[sbase + ii] : lse_t[sbase + ii];
@@ -482,11 +520,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_k(
       for (int k2 = 0; k2 < 2; ++k2) {
         const uint4 pf = frag(myPT, LDP, 0, 32 * k2, lane);
         const uint4 sf = frag(myST, LDP, 0, 32 * k2, lane);
+        uint4 t8[8];
+        frags_tr8(sdO, 32 * k2, lane, t8);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          dv[d] = mma(pf, frag(sdOT, LDT, 16 * d, 32 * k2, lane), dv[d]);
-          dk[d] = mma(sf, frag(sQT, LDT, 16 * d, 32 * k2, lane), dk[d]);
-        }
+        for (int d = 0; d < 8; ++d) dv[d] = mma(pf, t8[d], dv[d]);
+        frags_tr8(sQ, 32 * k2, lane, t8);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dk[d] = mma(sf, t8[d], dk[d]);
       }
     }
   }
@@ -533,8 +573,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_k(
 }
 
 constexpr size_t FWD_LDS = (size_t)(KT * LDR + DH * LDT + 4 * 16 * LDP) * 2;
-constexpr size_t DQ_LDS = (size_t)(2 * KT * LDR + DH * LDT + 4 * 16 * LDP) * 2;
-constexpr size_t DKV_LDS_A = (size_t)(2 * KT * LDR + 2 * DH * LDT + 4 * 2 * 16 * LDP) * 2 + 2 * KT * 4;
+constexpr size_t FWD_LDS_TR = (size_t)(2 * KT * LDR + 4 * 16 * LDP) * 2;
+constexpr size_t DQ_LDS = (size_t)(2 * KT * LDR + 4 * 16 * LDP) * 2;
+constexpr size_t DKV_LDS_A = (size_t)(2 * KT * LDR + 4 * 2 * 16 * LDP) * 2 + 2 * KT * 4;
 constexpr size_t DKV_LDS_B = (size_t)2 * 4 * 16 * DH * 4;
 constexpr size_t DKV_LDS = DKV_LDS_A > DKV_LDS_B ? DKV_LDS_A : DKV_LDS_B;
 
@@ -544,10 +585,14 @@ constexpr size_t DKV_LDS = DKV_LDS_A > DKV_LDS_B ? DKV_LDS_A : DKV_LDS_B;
 int fvqa_attn_fwd_mfma(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1, const float* gate2,
                        const int32_t* vstart, int n_seq, int S, int H, int A, int F, hipStream_t st) {
   const int nqb = (S + QB - 1) / QB;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS); attr = true; }
-  hipLaunchKernelGGL(attn_fwd_mfma_k, dim3(nqb, H, n_seq), dim3(256), FWD_LDS, st, (const bf16_t*)qkv, (bf16_t*)o,
-                     lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, A, F);
+  static const bool tr = [] { const char* e = getenv("FVQA_ATTN_TR"); return !(e && e[0] == '0'); }();
+  if (tr) {
+    hipLaunchKernelGGL(attn_fwd_mfma_k<true>, dim3(nqb, H, n_seq), dim3(256), FWD_LDS_TR, st, (const bf16_t*)qkv,
+                       (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, A, F);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_mfma_k<false>, dim3(nqb, H, n_seq), dim3(256), FWD_LDS, st, (const bf16_t*)qkv,
+                       (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, A, F);
+  }
   return 0;
 }
 

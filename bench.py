@@ -63,13 +63,17 @@ def cpu_baseline_leg(seq_len, max_feats):
         model = ref_cpu.RefModel(cfg, synth.state_dict(cfg), dtype=torch.float32)
         batch = synth.make_batch(cfg, seed=0)
         model.step(batch)                      # warm-up
-        t0 = time.perf_counter()
-        reps = 2
-        for _ in range(reps):
+        best = float("inf")
+        for _ in range(3):                     # min of 3: host timings on a shared box are noisy
+            t0 = time.perf_counter()
             model.step(batch)
-        times[L] = (time.perf_counter() - t0) / reps
+            best = min(best, time.perf_counter() - t0)
+        times[L] = best
         del model
-    per_layer = max(times[2] - times[1], 1e-9)
+    # two-point fit: fixed cost (embedding, LM head, CE) + per-layer cost; guarded against noise
+    per_layer = times[2] - times[1]
+    if not (0.15 * times[2] < per_layer < times[1]):
+        per_layer = times[2] / 3.0
     fixed = max(times[1] - per_layer, 0.0)
     full = fixed + 32 * per_layer              # one 7B step on B=2 samples
     return {"value": 2.0 / full, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
 #endif
   const int nk_all = K / KE;
   // K range of this split in stages; the wide-row loop eats stages in pairs, so its ranges are even
-  constexpr int KU = (PIPE == 2 || PIPE == 3) ? 2 : 1;
+  constexpr int KU = (PIPE == 2 || PIPE == 3 || PIPE == 6) ? 2 : 1;
   const int kbeg = KU * (int)(((long long)(nk_all / KU) * sp) / splits);
   const int kend = KU * (int)(((long long)(nk_all / KU) * (sp + 1)) / splits);
   const int nk = kend - kbeg;
@@ -159,6 +159,145 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
+  if constexpr (PIPE == 6) {
+    // Mode 3 plus a half-stage STAGGER: waves 4-7 (the second wave on every SIMD) run k-step 1 of
+    // each stage after the next stage's barrier, from fragments they read (and waited for) before it.
+    // While waves 0-3 sit in the LDS latency that follows a barrier, waves 4-7 have 32 MFMAs queued,
+    // so the matrix pipe does not drain at every stage boundary (MI355X_MICROARCH 'Two waves per SIMD' item 9).
+    // ---- wide-row asymmetric rings. Measured on MI355X (profiles/r01_gemm_ablation.log): with every
+    // workgroup streaming the same L2-resident tiles the DMA path alone runs 1.8 PF/s-equivalent, on
+    // the real operands 1.2 — the ring was waiting on HBM latency of the once-read WEIGHT panel, not
+    // on bandwidth. So the weight (B) operand gets a deeper ring than the activations (A, re-read
+    // by every N tile, served by L2 / Infinity Cache): A 2 x 32 KiB, B 3 x 32 KiB = 160 KiB.
+    // vmcnt retires in order per wave, so the two streams are issued by DIFFERENT waves: waves 0-3
+    // move A and wait vmcnt(0) for stage u; waves 4-7 move B two stages ahead and wait with one
+    // newer stage (8 loads) still in flight. One barrier per stage publishes both.
+    constexpr int WROW = 128, WOP = TM * WROW;            // 32 KiB per operand per stage
+    const int nw = nk / 2;
+    const bool bwave = w >= 4;                            // wave-uniform DMA role
+    const int wq = w & 3;
+    const T* wsrc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int piece = wq * 8 + t;                       // 32 pieces of 8 rows x 128 B per operand
+      const int row = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      int ga = m0 + row; ga = ga < M ? ga : M - 1;
+      int gb = n0 + row; gb = gb < N ? gb : N - 1;
+      wsrc[t] = bwave ? B + (size_t)gb * ldb + (size_t)kbeg * KE + c * CH
+                      : A + (size_t)ga * lda + (size_t)kbeg * KE + c * CH;
+    }
+    char* const ringA = smem;                             // 2 slots
+    char* const ringB = smem + 2 * WOP;                   // 3 slots
+    // piece q (0..7) of this wave's operand for stage u; slot = ring slot of that stage
+    auto issue_piece = [&](int u, int slot, int q) {
+      char* d = (bwave ? ringB : ringA) + slot * WOP + (wq * 8 + q) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + (size_t)u * 2 * KE),
+                                       (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    };
+    const int fsw = lane & 7, fkc = lane >> 4;
+    const unsigned rowA = (unsigned)((wr * 128 + frow) * WROW);
+    const unsigned rowB = (unsigned)(2 * WOP + (wc * 64 + frow) * WROW);
+    const unsigned ck0 = (unsigned)(((0 + fkc) ^ fsw) << 4), ck1 = (unsigned)(((4 + fkc) ^ fsw) << 4);
+#define FVQA_WREAD(A_, B_, pa0, pb0, ck)                                                                     \
+  {                                                                                                          \
+    const unsigned pa_ = (pa0) + (ck), pb_ = (pb0) + (ck);                                                   \
+    FVQA_DSR(B_[0], pb_, 0);    FVQA_DSR(B_[1], pb_, 2048);  FVQA_DSR(B_[2], pb_, 4096);  FVQA_DSR(B_[3], pb_, 6144);  \
+    FVQA_DSR(A_[0], pa_, 0);    FVQA_DSR(A_[1], pa_, 2048);  FVQA_DSR(A_[2], pa_, 4096);  FVQA_DSR(A_[3], pa_, 6144);  \
+    FVQA_DSR(A_[4], pa_, 8192); FVQA_DSR(A_[5], pa_, 10240); FVQA_DSR(A_[6], pa_, 12288); FVQA_DSR(A_[7], pa_, 14336); \
+  }
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 1)
+#define FVQA_WROW(i, n)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
+  asm volatile("" ::"v"(a[i]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));            \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define FVQA_WROW(i, n)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
+  Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
+  Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 2)
+#define FVQA_WROW_DMA(i, n, q) FVQA_WROW(i, n)
+#else
+#define FVQA_WROW_DMA(i, n, q)                                                         \
+  FVQA_WROW(i, n)                                                                      \
+  if (more) issue_piece(nu, nslot, q);                                                 \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+    // prologue: A stage 0; B stages 0 and 1
+    if (nw > 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) issue_piece(0, 0, q);
+      if (bwave && nw > 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_piece(1, 1, q);
+      }
+    }
+    int sa = 0, sbs = 0;                                  // ring slots of stage u: u % 2, u % 3
+    const bool late = w >= 4;                             // wave-uniform
+    // k-step-1 fragments of output rows 0-63 (B + first four A rows): consumed at once by waves 0-3,
+    // held across the next barrier by waves 4-7 (16 deferred MFMAs = 256 cycles of cover)
+    u32x4 hl[4], hb[4];
+#define FVQA_HROW(i)                                                                   \
+  Mma256<T>::run(hl[i], hb[0], acc[i][0]); Mma256<T>::run(hl[i], hb[1], acc[i][1]);    \
+  Mma256<T>::run(hl[i], hb[2], acc[i][2]); Mma256<T>::run(hl[i], hb[3], acc[i][3]);
+#define FVQA_UROW(i)                                                                   \
+  Mma256<T>::run(au[i - 4], hb[0], acc[i][0]); Mma256<T>::run(au[i - 4], hb[1], acc[i][1]); \
+  Mma256<T>::run(au[i - 4], hb[2], acc[i][2]); Mma256<T>::run(au[i - 4], hb[3], acc[i][3]);
+    for (int u = 0; u < nw; ++u) {
+      if (bwave && u + 1 < nw) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // B(u) landed, B(u+1) in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // stage u published; slots of stage u-1 are free
+      asm volatile("" ::: "memory");
+      const int nu = bwave ? u + 2 : u + 1;
+      const int nslot = bwave ? (sbs == 0 ? 2 : sbs - 1) : (sa ^ 1);
+      const bool more = nu < nw;
+      const unsigned pa0 = lds0 + (unsigned)(sa * WOP) + rowA;
+      const unsigned pb0 = lds0 + (unsigned)(sbs * WOP) + rowB;
+      if (late && u > 0) {                                // deferred rows 0-63 of stage u-1, k-step 1
+        FVQA_HROW(0) FVQA_HROW(1) FVQA_HROW(2) FVQA_HROW(3)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        u32x4 a[8], b[4];
+        FVQA_WREAD(a, b, pa0, pb0, ck0);
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        FVQA_WROW_DMA(0, 7, 0) FVQA_WROW_DMA(1, 6, 1) FVQA_WROW_DMA(2, 5, 2) FVQA_WROW_DMA(3, 4, 3)
+        FVQA_WROW_DMA(4, 3, 4) FVQA_WROW_DMA(5, 2, 5) FVQA_WROW_DMA(6, 1, 6) FVQA_WROW_DMA(7, 0, 7)
+      }
+      {
+        u32x4 au[4];
+        const unsigned pa_ = pa0 + ck1, pb_ = pb0 + ck1;
+        FVQA_DSR(hb[0], pb_, 0);    FVQA_DSR(hb[1], pb_, 2048);  FVQA_DSR(hb[2], pb_, 4096);  FVQA_DSR(hb[3], pb_, 6144);
+        FVQA_DSR(au[0], pa_, 8192); FVQA_DSR(au[1], pa_, 10240); FVQA_DSR(au[2], pa_, 12288); FVQA_DSR(au[3], pa_, 14336);
+        FVQA_DSR(hl[0], pa_, 0);    FVQA_DSR(hl[1], pa_, 2048);  FVQA_DSR(hl[2], pa_, 4096);  FVQA_DSR(hl[3], pa_, 6144);
+        asm volatile("s_waitcnt lgkmcnt(4)"
+                     : "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]), "+v"(au[0]), "+v"(au[1]), "+v"(au[2]),
+                       "+v"(au[3]));
+        FVQA_UROW(4) FVQA_UROW(5) FVQA_UROW(6) FVQA_UROW(7)
+        __builtin_amdgcn_sched_barrier(0);
+        // retire the reads of rows 0-63 before the next barrier (their slot may be refilled after it)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hl[0]), "+v"(hl[1]), "+v"(hl[2]), "+v"(hl[3]));
+        if (!late) {
+          FVQA_HROW(0) FVQA_HROW(1) FVQA_HROW(2) FVQA_HROW(3)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("" ::: "memory");
+      sa ^= 1;
+      sbs = (sbs == 2) ? 0 : sbs + 1;
+    }
+    if (late && nw > 0) {
+      FVQA_HROW(0) FVQA_HROW(1) FVQA_HROW(2) FVQA_HROW(3)
+    }
+#undef FVQA_UROW
+#undef FVQA_HROW
+#undef FVQA_WROW_DMA
+#undef FVQA_WROW
+#undef FVQA_WREAD
+  } else
   if constexpr (PIPE == 3) {
     // ---- wide-row asymmetric rings. Measured on MI355X (profiles/r01_gemm_ablation.log): with every
     // workgroup streaming the same L2-resident tiles the DMA path alone runs 1.8 PF/s-equivalent, on
@@ -537,7 +676,7 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
                int lda, int ldb, int ldc, int m_split, int splits, bool partial_only, hipStream_t st) {
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
   dim3 grid(tm * tn * splits), block(512);
-  constexpr int LDSB = (PIPE == 3 ? 5 : PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
+  constexpr int LDSB = ((PIPE == 3 || PIPE == 6) ? 5 : PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
   if (splits > 1 || partial_only) {
     auto k = gemm_nt_256<T, TO, EPI, true, PIPE>;
     static bool attr_done = false;
@@ -638,6 +777,7 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
 #define GO(T, TO)                     \
   if (mode == 2) { GO2(T, TO, 2); }   \
   if (mode == 3) { GO2(T, TO, 3); }   \
+  if (mode == 6) { GO2(T, TO, 6); }   \
   if (mode == 5) { GO2(T, TO, 5); }   \
   if (mode == 4) { GO2(T, TO, 4); }   \
   GO2(T, TO, 0)

@@ -51,7 +51,7 @@ def test_gemm_nt(dtype, variant, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7, 8, 17, 18, 19, 20])   # 256x256 ring kernel: loops / 1..4 K-splits
+@pytest.mark.parametrize("variant", [3, 4, 5, 6, 7, 8, 9, 17, 18, 19, 20])   # 256x256 ring kernel: loops / 1..4 K-splits
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1034, 512, 1024), (300, 768, 2112), (1024, 4096, 4096)])
 def test_gemm_nt_256_ring_and_splitk(dtype, variant, M, N, K):
     if (M, N, K) == (1024, 4096, 4096) and dtype == torch.float32 and variant not in (3, 6, 20):
@@ -91,7 +91,7 @@ def test_gemm_nt_identity_asymmetric(dtype):
     M = N = K = 128
     a = torch.eye(M, K, dtype=dtype)
     b = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 0.5).to(dtype)     # exactly representable
-    for variant in (2, 3, 4, 5, 6, 7, 8, 18):
+    for variant in (2, 3, 4, 5, 6, 7, 8, 9, 18):
         out = torch.empty(M, N, dtype=torch.float32, device=DEV)
         ops.gemm_nt(dev(a), dev(b), out, variant=variant)
         assert torch.equal(out.cpu(), b.float().T.contiguous()), variant

@@ -211,7 +211,7 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
 
 // variant: 0 = auto (256x256 ring kernel with automatic split-K when the problem is large enough,
 // else the 128x128 kernel); 1 = 128x128 register-staged; 2 = 128x128 LDS-DMA; 3 = 256x256 default
-// loop; 4 = 256x256 plain ring loop; 5 / 6 = 256x256 software-pipelined loop on a 4- / 5-deep ring;
+// loop; 4 = 256x256 plain 64-byte-row ring loop;
 // 7 = 256x256 wide-row (128-byte) two-stage ring; 8 = wide-row asymmetric rings (A x2, B x3, role-split DMA); 9 = the same with waves 4-7 staggered by half a stage;
 // 16+s = 256x256 default loop with exactly s K-splits (tests / tuning).
 extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail, int M, int N,
@@ -219,8 +219,11 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
                             int variant, void* workspace, size_t workspace_bytes, void* stream) {
   if (!A || !B || (!C && epilogue != FVQA_EPI_PARTIAL)) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype) || !fvqa_dtype_ok(out_dtype)) return FVQA_EINVAL;
-  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_PARTIAL) return FVQA_EINVAL;
-  if (epilogue == FVQA_EPI_RESIDUAL && (!R || out_dtype != dtype)) return FVQA_EINVAL;
+  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_PARTIAL &&
+      epilogue != FVQA_EPI_SWIGLU_BWD)
+    return FVQA_EINVAL;
+  if ((epilogue == FVQA_EPI_RESIDUAL || epilogue == FVQA_EPI_SWIGLU_BWD) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
+  if (epilogue == FVQA_EPI_SWIGLU_BWD && (tail || ldc != 2 * N)) return FVQA_EINVAL;
   if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return FVQA_ESHAPE;
   const int ke = dtype == FVQA_BF16 ? 64 : 32;
@@ -230,9 +233,9 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
     return FVQA_EALIGN;
   if (lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const bool big = epilogue == FVQA_EPI_PARTIAL || (variant >= 3 && variant <= 9) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
+  const bool big = epilogue == FVQA_EPI_PARTIAL || epilogue == FVQA_EPI_SWIGLU_BWD || (variant >= 3 && variant <= 9 && variant != 5 && variant != 6) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
   if (big) {
-    const int mode = variant == 4 ? 0 : variant == 5 ? 4 : variant == 6 ? 5 : variant == 7 ? 2 : variant == 8 ? 3 : variant == 9 ? 6 : FVQA_GEMM256_DEFAULT_MODE;
+    const int mode = variant == 4 ? 0 : variant == 7 ? 2 : variant == 8 ? 3 : variant == 9 ? 6 : FVQA_GEMM256_DEFAULT_MODE;
     return fvqa_gemm_nt_256_impl(A, B, C, R, tail, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, m_split, dtype,
                                  out_dtype, epilogue, variant >= 16 ? variant - 16 : 0, mode, st);
   }

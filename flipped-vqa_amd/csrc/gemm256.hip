@@ -59,9 +59,9 @@ __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
 }
 
 // EPI: 0 none, 1 residual. SPLIT: write fp32 partials to `ws` instead of C.
-// PIPE: 0 = plain ring loop (fragments read and consumed in the same stage);
-//       NS (4 or 5) = software-pipelined loop over an NS-deep ring: the fragments of stage t+1 are
-//       read into a second register set while the 32 MFMAs of stage t run.
+// PIPE (loop structure): 0 = 64-byte rows, symmetric 4-slot ring (kept for ablation);
+//       2 = 128-byte rows, 2-slot ring; 3 = 128-byte rows, asymmetric A/B rings with role-split DMA;
+//       6 = 3 plus the half-stage stagger of waves 4-7 (default).
 template <typename T, typename TO, int EPI, bool SPLIT, int PIPE>
 __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, const T* __restrict__ B,
                                                    TO* __restrict__ C, const T* __restrict__ R,
@@ -533,79 +533,6 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     asm volatile("" ::: "memory");
   }
 #undef FVQA_ROW
-  } else {
-    // Software-pipelined loop. A stage is consumed in two halves of 16 MFMAs (output rows 0-63 and
-    // 64-127 of the wave); the LDS reads of the NEXT half are always issued before the MFMAs of the
-    // current half, so every counted lgkmcnt wait sits behind >= 256 MFMA cycles of cover:
-    //   top of stage t : [b, aL of stage t in flight]  read aH(t) ; wait(b,aL) ; 16 MFMA (rows 0-63)
-    //   middle         : wait my DMA(t+1) ; s_barrier ; issue DMA(t+NS-1) ; read b',aL'(t+1) ;
-    //                    wait(aH) ; 16 MFMA (rows 64-127)
-    // The barrier publishes stage t+1 and retires every wave's reads of stage t-1 (they were waited
-    // for before that wave's MFMAs of stage t-1), whose ring slot the new DMA overwrites.
-    constexpr int NS = PIPE;
-#pragma unroll
-    for (int s0 = 0; s0 < NS - 1; ++s0)
-      if (s0 < nk) issue_slot(s0, s0);
-    wait_dma(min(nk, NS - 1) - 1);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    u32x4 b0[4], b1[4], l0[4], l1[4], hh[4];
-#define FVQA_READ_H1(B_, L_, slot)                                                                          \
-  {                                                                                                          \
-    const unsigned sb_ = lds0 + (unsigned)((slot) * STAGE);                                                  \
-    const unsigned pa_ = sb_ + (unsigned)offA, pb_ = sb_ + (unsigned)offB;                                   \
-    FVQA_DSR(B_[0], pb_, 0); FVQA_DSR(B_[1], pb_, 1024); FVQA_DSR(B_[2], pb_, 2048); FVQA_DSR(B_[3], pb_, 3072); \
-    FVQA_DSR(L_[0], pa_, 0); FVQA_DSR(L_[1], pa_, 1024); FVQA_DSR(L_[2], pa_, 2048); FVQA_DSR(L_[3], pa_, 3072); \
-  }
-#define FVQA_READ_H2(H_, slot)                                                                              \
-  {                                                                                                          \
-    const unsigned pa_ = lds0 + (unsigned)((slot) * STAGE) + (unsigned)offA;                                 \
-    FVQA_DSR(H_[0], pa_, 4096); FVQA_DSR(H_[1], pa_, 5120); FVQA_DSR(H_[2], pa_, 6144); FVQA_DSR(H_[3], pa_, 7168); \
-  }
-#define FVQA_MMA16(A_, B_, r0)                                                                \
-  _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
-    Mma256<T>::run(A_[i_], B_[0], acc[r0 + i_][0]); Mma256<T>::run(A_[i_], B_[1], acc[r0 + i_][1]); \
-    Mma256<T>::run(A_[i_], B_[2], acc[r0 + i_][2]); Mma256<T>::run(A_[i_], B_[3], acc[r0 + i_][3]); \
-  }
-#define FVQA_STEP(CB, CL, NB, NL, MORE)                                                                      \
-  {                                                                                                          \
-    FVQA_READ_H2(hh, rs);                                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(4)"                                                                      \
-                 : "+v"(CB[0]), "+v"(CB[1]), "+v"(CB[2]), "+v"(CB[3]), "+v"(CL[0]), "+v"(CL[1]), "+v"(CL[2]), \
-                   "+v"(CL[3]));                                                                             \
-    FVQA_MMA16(CL, CB, 0)                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    if (MORE) {                                                                                              \
-      wait_dma(min(nk - t - 2, NS - 3));                                                                     \
-      __builtin_amdgcn_s_barrier();                                                                          \
-      asm volatile("" ::: "memory");                                                                         \
-      if (t + NS - 1 < nk) issue_slot(t + NS - 1, is);                                                       \
-      rs = (rs + 1 == NS) ? 0 : rs + 1;                                                                      \
-      FVQA_READ_H1(NB, NL, rs);                                                                              \
-      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hh[2]), "+v"(hh[3]));             \
-    } else {                                                                                                 \
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hh[2]), "+v"(hh[3]));             \
-    }                                                                                                        \
-    is = (is + 1 == NS) ? 0 : is + 1;                                                                        \
-    FVQA_MMA16(hh, CB, 4)                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    ++t;                                                                                                     \
-  }
-    int rs = 0;            // ring slot of stage t
-    int is = NS - 1;       // ring slot the next DMA goes to: (t + NS - 1) % NS
-    int t = 0;
-    if (nk > 0) {
-      FVQA_READ_H1(b0, l0, 0);
-      // two stages per trip so that the two fragment register sets alternate statically
-      while (t < nk) {
-        FVQA_STEP(b0, l0, b1, l1, (t + 1 < nk))
-        if (t < nk) FVQA_STEP(b1, l1, b0, l0, (t + 1 < nk))
-      }
-    }
-#undef FVQA_STEP
-#undef FVQA_MMA16
-#undef FVQA_READ_H2
-#undef FVQA_READ_H1
   }
 #undef FVQA_READ12
 #undef FVQA_DSR
@@ -629,8 +556,17 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
         } else if (tail != nullptr && m >= m_split) {
           tail[(size_t)(m - m_split) * N + n] += v;
         } else {
-          if (EPI == FVQA_EPI_RESIDUAL) v += to_f32<T>(R[(size_t)m * ldc + n]);
-          C[(size_t)m * ldc + n] = from_f32<TO>(v);
+          if (EPI == FVQA_EPI_SWIGLU_BWD) {
+            // v = dz[m][n]; R = ab (rows of 2N: a | b); C = dab (rows of 2N): d(silu(a)*b)
+            const size_t o = (size_t)m * 2 * N + n;
+            const float a_ = to_f32<T>(R[o]), b_ = to_f32<T>(R[o + N]);
+            const float sg = 1.f / (1.f + __expf(-a_));
+            C[o] = from_f32<TO>(v * b_ * sg * (1.f + a_ * (1.f - sg)));
+            C[o + N] = from_f32<TO>(v * a_ * sg);
+          } else {
+            if (EPI == FVQA_EPI_RESIDUAL) v += to_f32<T>(R[(size_t)m * ldc + n]);
+            C[(size_t)m * ldc + n] = from_f32<TO>(v);
+          }
         }
       }
     }
@@ -749,6 +685,13 @@ extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
 int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, float* tail, void* ws,
                           size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
                           int out_dtype, int epilogue, int force_splits, int mode, hipStream_t st) {
+  if (epilogue == FVQA_EPI_SWIGLU_BWD) {       // elementwise epilogue on whole outputs: no K split
+    if (dtype == FVQA_BF16)
+      return launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda, ldb,
+                                                               ldc, m_split, 1, false, st);
+    return launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda, ldb, ldc,
+                                                           m_split, 1, false, st);
+  }
   int splits = force_splits > 0 ? force_splits : fvqa_gemm_splits(M, N, K, dtype);
   const bool partial = epilogue == FVQA_EPI_PARTIAL;
   if (!partial && force_splits == 0 && splits == 1 && tail == nullptr && ws != nullptr) {
@@ -778,8 +721,6 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
   if (mode == 2) { GO2(T, TO, 2); }   \
   if (mode == 3) { GO2(T, TO, 3); }   \
   if (mode == 6) { GO2(T, TO, 6); }   \
-  if (mode == 5) { GO2(T, TO, 5); }   \
-  if (mode == 4) { GO2(T, TO, 4); }   \
   GO2(T, TO, 0)
   if (dtype == FVQA_BF16) {
     if (out_dtype == FVQA_F32) { GO(bf16_t, float); }

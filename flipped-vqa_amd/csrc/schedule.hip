@@ -10,7 +10,7 @@
 //   fwd: [xn = RMSNorm(x)] -> adapter rows -> QKV GEMM -> RoPE -> attention -> WO GEMM (split-K
 //        partials) -> fused residual+RMSNorm -> W1|W3 GEMM -> SwiGLU -> W2 GEMM (partials) -> fused
 //        residual+RMSNorm of the NEXT layer (or the final norm)
-//   bwd: W2^T GEMM -> SwiGLU' -> W1|W3^T GEMM (partials) -> fused RMSNorm' (+residual grad) ->
+//   bwd: W2^T GEMM with SwiGLU' epilogue -> W1|W3^T GEMM (partials) -> fused RMSNorm' (+residual grad) ->
 //        WO^T GEMM -> attention' -> RoPE^-1 -> QKV^T GEMM (partials, adapter-gradient tail rows) ->
 //        fused RMSNorm' (+residual grad)
 #include "common.h"
@@ -135,9 +135,9 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     const void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
     const float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
     const float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
-    RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dz, nullptr, nullptr, R, Hf, D, D, D, Hf, R, dt, dt, FVQA_EPI_NONE, 0,
+    // dz = cur·W2 never reaches HBM: the SwiGLU backward is this GEMM's epilogue
+    RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dab, ab, nullptr, R, Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_SWIGLU_BWD, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
-    RUN(fvqa_swiglu_bwd(p->dz, ab, p->dab, R, Hf, dt, stream));
     int sp = fvqa_gemm_splits(R, D, 2 * Hf, dt);
     RUN(fvqa_gemm_nt(p->dab, p->w13_t[i], nullptr, nullptr, nullptr, R, D, 2 * Hf, 2 * Hf, 2 * Hf, D, R, dt, dt,
                      FVQA_EPI_PARTIAL, 0, p->gemm_ws, p->gemm_ws_bytes, stream));

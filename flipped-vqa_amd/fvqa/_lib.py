@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL = 0, 1, 2
+EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL, EPI_SWIGLU_BWD = 0, 1, 2, 3
 ABI_VERSION = 4
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_NONE, EPI_PARTIAL, EPI_RESIDUAL, F32
+from ._lib import BF16, EPI_NONE, EPI_PARTIAL, EPI_RESIDUAL, EPI_SWIGLU_BWD, F32
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _DTN = {torch.float32: "f32", torch.bfloat16: "bf16"}
@@ -94,7 +94,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
     code = dt_code(a.dtype)
     if variant >= 16:
         need = (variant - 16) * M * N * 4 if variant > 17 else 0
-    elif variant in (0, 3, 4, 5, 6, 7, 8, 9):
+    elif variant in (0, 3, 4, 7, 8, 9):
         need = int(lib.fvqa_gemm_workspace(M, N, K, code))
     else:
         need = 0
@@ -138,6 +138,29 @@ def gemm_nt_partial(a: torch.Tensor, b: torch.Tensor):
         timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[a.dtype]}_none_partial"))
     _lib.check(rc, "fvqa_gemm_nt(partial)")
     return ws[:need].view(torch.float32).view(splits, M, N), splits
+
+
+def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, dab: torch.Tensor):
+    """dab (M, 2*Hf) = d/d(a,b)[silu(a)*b] with dz = g (M,D) @ w2_t (Hf,D)^T formed in the GEMM
+    accumulators (the SwiGLU backward is the GEMM's epilogue; dz never reaches HBM)."""
+    _dev(g, w2_t, ab, dab)
+    M, K = g.shape
+    N = w2_t.shape[0]
+    _need(w2_t.shape[1] == K and g.dtype == w2_t.dtype == ab.dtype == dab.dtype, "gemm_nt_swiglu_bwd: operands")
+    _need(ab.numel() >= M * 2 * N and dab.numel() >= M * 2 * N and ab.shape[-1] == 2 * N and dab.shape[-1] == 2 * N,
+          "gemm_nt_swiglu_bwd: ab/dab shape")
+    lib = _lib.load()
+    timing = GEMM_TIMING
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.fvqa_gemm_nt(_ptr(g), _ptr(w2_t), _ptr(dab), _ptr(ab), None, M, N, K, K, K, 2 * N, M, dt_code(g.dtype),
+                          dt_code(g.dtype), EPI_SWIGLU_BWD, 0, None, 0, _stream())
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[g.dtype]}_{_DTN[g.dtype]}_swiglu_plain"))
+    _lib.check(rc, "fvqa_gemm_nt(swiglu_bwd)")
+    return dab
 
 
 # ------------------------------------------------------------------------------------ row ops

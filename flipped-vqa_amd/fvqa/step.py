@@ -362,8 +362,7 @@ class StepEngine:
         ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
         g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
         for i in reversed(range(L)):
-            ops.gemm_nt(cur, pk.w2_t[i], ar.dz)
-            ops.swiglu_bwd(ar.dz, ar.ab[i], ar.dab, R, Hf)
+            ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab)      # dz·SwiGLU' fused in the epilogue
             ws, _ = ops.gemm_nt_partial(ar.dab, pk.w13_t[i])
             ops.sum_rmsnorm_bwd(ws, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, R, resid=cur)
             ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)

@@ -39,6 +39,8 @@ extern "C" {
 /* GEMM epilogue selector */
 #define FVQA_EPI_NONE 0
 #define FVQA_EPI_RESIDUAL 1 /* C = acc + R                                  */
+#define FVQA_EPI_SWIGLU_BWD 3 /* acc = dz (M,N): R = ab (M,2N: a|b), C = dab (M,2N) <- d/d(a,b) of
+                                silu(a)*b (llama/model.py:142 backward); ldc must be 2N     */
 #define FVQA_EPI_PARTIAL 2  /* no C: leave the fp32 split-K partial sums [splits][M][N] in
                                `workspace` for a fused consumer (fvqa_sumres_rmsnorm_fwd,
                                fvqa_sum_rmsnorm_bwd); splits = fvqa_gemm_splits(M,N,K,dtype) */

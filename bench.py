@@ -214,7 +214,7 @@ def main():
                 traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
                 tsrc = "profiles/r01_pmc_gemm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, same workload)"
             roof = {"bound": "mfma",
-                    "kernel": "gemm_nt_256<bf16,bf16,EPI_NONE,{plain|split-K partial},ring=3>" if a.dtype == "bf16" else "gemm_nt_256<f32>",
+                    "kernel": "gemm_nt_256<bf16,bf16,EPI_NONE,{plain|split-K partial},mode6 A2/B3 ring + stagger>" if a.dtype == "bf16" else "gemm_nt_256<f32>",
                     "achieved": tot_f / tot_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": tot_f / tot_t / peak, "traffic": traffic, "traffic_source": tsrc,
                     "launches_per_step": n // a.steps, "avg_launch_us": tot_t / n * 1e6,

@@ -21,6 +21,7 @@
 // 256 CUs) are split along K over blockIdx ranges; partial sums go to an fp32 workspace
 // [split][M][N] and `splitk_fixup` adds them (+ residual, fp32 tail rows) in one pass.
 #include "common.h"
+#include <vector>
 
 namespace {
 
@@ -34,23 +35,47 @@ constexpr int STAGE = 2 * STAGE_OP;      // 32 KiB
 constexpr int NSTAGE = 4;                // ring depth of the plain loop (PIPE == 0)
 constexpr int LDS256 = NSTAGE * STAGE;   // 128 KiB
 
+// run(a, b, acc) feeds the WEIGHT fragment as the MFMA's row operand and the activation fragment as
+// its column operand, i.e. each 16x16 block is produced transposed: lane l then holds
+// out[m = l&15][n = 4*(l>>4) .. +3] — four CONSECUTIVE output columns per lane, so the epilogue
+// moves 8/16-byte vectors (C, partial sums, the SwiGLU' operands) instead of 2/4-byte scalars.
 template <typename T> struct Mma256;
 template <> struct Mma256<bf16_t> {
   static constexpr int KE = 32;          // elements per stage
   static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                  __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b),
+                                                  __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
   }
 };
 template <> struct Mma256<float> {
   static constexpr int KE = 16;
   static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(b.x), __uint_as_float(a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(b.y), __uint_as_float(a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(b.z), __uint_as_float(a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(b.w), __uint_as_float(a.w), acc, 0, 0, 0);
   }
 };
+
+__device__ __forceinline__ void unpack8_bf16(const uint4& q, float (&v)[8]) {
+  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xFFFF0000u);
+  v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xFFFF0000u);
+  v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xFFFF0000u);
+}
+template <typename TO> __device__ __forceinline__ void store8(TO* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 t;
+  t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+  t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+  t.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
+  t.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = t;
+}
 
 __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -537,35 +562,199 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
 #undef FVQA_READ12
 #undef FVQA_DSR
 
-  // ---- epilogue (C/D map: col = lane&15, row = (lane>>4)*4 + reg)
-  const int ccol = lane & 15;
-  const int crow = (lane >> 4) * 4;
+  // ---- epilogue (transposed C/D map: m = lane&15, n = (lane>>4)*4 + reg; see Mma256)
+  const int crow = lane & 15;
+  const int ccol = (lane >> 4) * 4;
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 64)
+  {                                    // timing experiment: no epilogue traffic (one never-taken store keeps acc live)
+    float s_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s_ == 1.2345678e-30f) ws[0] = s_;
+    return;
+  }
+#endif
+  // Wide path: the accumulators make one round trip through LDS (free once the ring has drained) so
+  // that every store instruction covers whole 128-byte lines: 8 lanes per row, 16 bytes per lane
+  // (measured: split-K partial stores 16 -> 10 us per launch against 4-column fragments).
+  // Each wave stages its own 128 x 64 tile in two 64-row passes through a private 16 KiB region;
+  // 16-byte chunk c of row r sits at chunk c ^ (r & 15), which keeps both the fragment writes (16 rows,
+  // one chunk) and the row reads (2 rows x 8 chunks per 16 lanes) free of bank conflicts.
+  //   4-byte outputs: lane k of a row owns columns 4k..4k+3 and 32+4k..32+4k+3 (two full lines per row);
+  //   2-byte outputs: lane k owns columns 8k..8k+7 (one full line per row).
+  const bool wide_ok = tail == nullptr && ((N & 7) == 0) && ((ldc & 7) == 0) &&
+                       ((((uintptr_t)C | (uintptr_t)R | (uintptr_t)ws) & 15) == 0);
+  if (wide_ok) {
+    constexpr bool W4 = SPLIT || sizeof(TO) == 4;
+    __syncthreads();                                   // every wave is done reading the ring
+    float* stg = reinterpret_cast<float*>(smem) + w * (64 * 64);
+    const int q = lane >> 3, k = lane & 7;
+    const int rl = W4 ? ((q & 1) * 8 + (q >> 1)) : q;  // row of this lane inside an 8-row group set
+    const int cA = W4 ? k : 2 * k, cB = W4 ? 8 + k : 2 * k + 1;
+    const int nA = n0 + wc * 64 + cA * 4, nB = n0 + wc * 64 + cB * 4;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int mb = m0 + wr * 128 + p * 64;
+      auto row_of = [&](int t) { return W4 ? 16 * (t >> 1) + 4 * (t & 1) + rl : 8 * t + rl; };
+      uint4 qa[8], qb[8];
+      if constexpr (!SPLIT && sizeof(T) == 2 && (EPI == FVQA_EPI_SWIGLU_BWD || EPI == FVQA_EPI_RESIDUAL)) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {                  // epilogue operands in flight before the staging
+          const int m = mb + row_of(t);
+          qa[t] = qb[t] = uint4{0u, 0u, 0u, 0u};
+          if (m < M && nA < N) {
+            if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
+              const T* rp = R + (size_t)m * 2 * N + nA;
+              qa[t] = *reinterpret_cast<const uint4*>(rp);
+              qb[t] = *reinterpret_cast<const uint4*>(rp + N);
+            } else {
+              qa[t] = *reinterpret_cast<const uint4*>(R + (size_t)m * ldc + nA);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(stg + (ii * 16 + crow) * 64 + (((j * 4 + (lane >> 4)) ^ crow) << 2)) =
+              acc[p * 4 + ii][j];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int r = row_of(t);
+        const int m = mb + r;
+        float v[8];
+        {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * 64 + ((cA ^ (r & 15)) << 2));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * 64 + ((cB ^ (r & 15)) << 2));
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+          v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        }
+        if (m >= M) continue;
+        float(&vA)[4] = reinterpret_cast<float(&)[4]>(v[0]);
+        float(&vB)[4] = reinterpret_cast<float(&)[4]>(v[4]);
+        if constexpr (SPLIT) {
+          float* wp = ws + ((size_t)sp * M + m) * N;
+          if (nA < N) Vec4<float>::store(wp + nA, vA);
+          if (nB < N) Vec4<float>::store(wp + nB, vB);
+        } else if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
+          const size_t o = (size_t)m * 2 * N;
+          float a_[8], b_[8], da[8], db[8];
+          if constexpr (sizeof(T) == 2) {
+            if (nA >= N) continue;
+            unpack8_bf16(qa[t], a_);
+            unpack8_bf16(qb[t], b_);
+          } else {
+            if (nA < N) { Vec4<T>::load(R + o + nA, reinterpret_cast<float(&)[4]>(a_[0]));
+                          Vec4<T>::load(R + o + N + nA, reinterpret_cast<float(&)[4]>(b_[0])); }
+            if (nB < N) { Vec4<T>::load(R + o + nB, reinterpret_cast<float(&)[4]>(a_[4]));
+                          Vec4<T>::load(R + o + N + nB, reinterpret_cast<float(&)[4]>(b_[4])); }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float sg = 1.f / (1.f + __expf(-a_[e]));
+            da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
+            db[e] = v[e] * a_[e] * sg;
+          }
+          if constexpr (sizeof(TO) == 2) {
+            store8<TO>(C + o + nA, da);
+            store8<TO>(C + o + N + nA, db);
+          } else {
+            if (nA < N) { Vec4<TO>::store(C + o + nA, reinterpret_cast<float(&)[4]>(da[0]));
+                          Vec4<TO>::store(C + o + N + nA, reinterpret_cast<float(&)[4]>(db[0])); }
+            if (nB < N) { Vec4<TO>::store(C + o + nB, reinterpret_cast<float(&)[4]>(da[4]));
+                          Vec4<TO>::store(C + o + N + nB, reinterpret_cast<float(&)[4]>(db[4])); }
+          }
+        } else {
+          TO* cp = C + (size_t)m * ldc;
+          if constexpr (EPI == FVQA_EPI_RESIDUAL) {
+            float r_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (sizeof(T) == 2) {
+              unpack8_bf16(qa[t], r_);
+            } else {
+              if (nA < N) Vec4<T>::load(R + (size_t)m * ldc + nA, reinterpret_cast<float(&)[4]>(r_[0]));
+              if (nB < N) Vec4<T>::load(R + (size_t)m * ldc + nB, reinterpret_cast<float(&)[4]>(r_[4]));
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r_[e];
+          }
+          if constexpr (sizeof(TO) == 2) {
+            if (nA < N) store8<TO>(cp + nA, v);
+          } else {
+            if (nA < N) Vec4<TO>::store(cp + nA, vA);
+            if (nB < N) Vec4<TO>::store(cp + nB, vB);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  const bool vec_ok = ((N & 3) == 0) && ((ldc & 3) == 0) &&
+                      ((((uintptr_t)C | (uintptr_t)R | (uintptr_t)ws | (uintptr_t)tail) & 15) == 0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + crow;
+    if (m >= M) continue;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int m = m0 + wr * 128 + i * 16 + crow + rg;
-      if (m >= M) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + ccol;
-        if (n >= N) continue;
-        float v = acc[i][j][rg];
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + ccol;
+      if (n >= N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (vec_ok) {                    // n % 4 == 0 and N % 4 == 0: the four columns are all inside
         if (SPLIT) {
-          ws[((size_t)sp * M + m) * N + n] = v;
+          Vec4<float>::store(ws + ((size_t)sp * M + m) * N + n, v);
         } else if (tail != nullptr && m >= m_split) {
-          tail[(size_t)(m - m_split) * N + n] += v;
+          float* tp = tail + (size_t)(m - m_split) * N + n;
+          float u[4];
+          Vec4<float>::load(tp, u);
+          u[0] += v[0]; u[1] += v[1]; u[2] += v[2]; u[3] += v[3];
+          Vec4<float>::store(tp, u);
+        } else if (EPI == FVQA_EPI_SWIGLU_BWD) {
+          // v = dz[m][n..n+3]; R = ab (rows of 2N: a | b); C = dab (rows of 2N): d(silu(a)*b)
+          const size_t o = (size_t)m * 2 * N + n;
+          float a_[4], b_[4], da[4], db[4];
+          Vec4<T>::load(R + o, a_);
+          Vec4<T>::load(R + o + N, b_);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sg = 1.f / (1.f + __expf(-a_[e]));
+            da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
+            db[e] = v[e] * a_[e] * sg;
+          }
+          Vec4<TO>::store(C + o, da);
+          Vec4<TO>::store(C + o + N, db);
         } else {
-          if (EPI == FVQA_EPI_SWIGLU_BWD) {
-            // v = dz[m][n]; R = ab (rows of 2N: a | b); C = dab (rows of 2N): d(silu(a)*b)
-            const size_t o = (size_t)m * 2 * N + n;
+          if (EPI == FVQA_EPI_RESIDUAL) {
+            float r[4];
+            Vec4<T>::load(R + (size_t)m * ldc + n, r);
+            v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+          }
+          Vec4<TO>::store(C + (size_t)m * ldc + n, v);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= N) continue;
+          if (SPLIT) {
+            ws[((size_t)sp * M + m) * N + n + e] = v[e];
+          } else if (tail != nullptr && m >= m_split) {
+            tail[(size_t)(m - m_split) * N + n + e] += v[e];
+          } else if (EPI == FVQA_EPI_SWIGLU_BWD) {
+            const size_t o = (size_t)m * 2 * N + n + e;
             const float a_ = to_f32<T>(R[o]), b_ = to_f32<T>(R[o + N]);
             const float sg = 1.f / (1.f + __expf(-a_));
-            C[o] = from_f32<TO>(v * b_ * sg * (1.f + a_ * (1.f - sg)));
-            C[o + N] = from_f32<TO>(v * a_ * sg);
+            C[o] = from_f32<TO>(v[e] * b_ * sg * (1.f + a_ * (1.f - sg)));
+            C[o + N] = from_f32<TO>(v[e] * a_ * sg);
           } else {
-            if (EPI == FVQA_EPI_RESIDUAL) v += to_f32<T>(R[(size_t)m * ldc + n]);
-            C[(size_t)m * ldc + n] = from_f32<TO>(v);
+            float x = v[e];
+            if (EPI == FVQA_EPI_RESIDUAL) x += to_f32<T>(R[(size_t)m * ldc + n + e]);
+            C[(size_t)m * ldc + n + e] = from_f32<TO>(x);
           }
         }
       }
@@ -607,18 +796,42 @@ __global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ ws
   }
 }
 
+// ---- measurement probe (include/fvqa.h: fvqa_gemm_timing_*)
+struct TimingRec { hipEvent_t e0, e1; double flops; int kind; };
+static std::vector<TimingRec> g_timing;
+static bool g_timing_on = false;
+struct TimingScope {
+  hipStream_t st; bool on; TimingRec r;
+  TimingScope(hipStream_t s, double flops, int kind) : st(s), on(g_timing_on) {
+    if (!on) return;
+    r.flops = flops; r.kind = kind;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(r.e0, st);
+  }
+  ~TimingScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.e1, st);
+    g_timing.push_back(r);
+  }
+};
+
 template <typename T, typename TO, int EPI, int PIPE>
 int launch_256(const void* A, const void* B, void* C, const void* R, float* tail, float* ws, int M, int N, int K,
                int lda, int ldb, int ldc, int m_split, int splits, bool partial_only, hipStream_t st) {
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
   dim3 grid(tm * tn * splits), block(512);
-  constexpr int LDSB = ((PIPE == 3 || PIPE == 6) ? 5 : PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
+  constexpr int RING = ((PIPE == 3 || PIPE == 6) ? 5 : PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
+  constexpr int STG = 8 * 64 * 64 * 4;                  // epilogue staging: 8 waves x 64 rows x 64 floats
+  constexpr int LDSB = RING > STG ? RING : STG;
   if (splits > 1 || partial_only) {
     auto k = gemm_nt_256<T, TO, EPI, true, PIPE>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
-    hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
-                       lda, ldb, ldc, m_split, tm, splits);
+    {
+      TimingScope ts(st, 2.0 * M * N * K, EPI | 16 | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
+      hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
+                         lda, ldb, ldc, m_split, tm, splits);
+    }
     if (!partial_only) {
       size_t n4 = (size_t)M * (N / 4);
       int g = (int)((n4 + 255) / 256);
@@ -630,6 +843,7 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
     auto k = gemm_nt_256<T, TO, EPI, false, PIPE>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
+    TimingScope ts(st, 2.0 * M * N * K, EPI | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
     hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
                        lda, ldb, ldc, m_split, tm, 1);
   }
@@ -638,6 +852,32 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
 }
 
 }  // namespace
+
+extern "C" int fvqa_gemm_timing_enable(int on) {
+  for (auto& r : g_timing) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_timing.clear();
+  g_timing_on = on != 0;
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_gemm_timing_read(int max, float* us, double* flops, int* kind) {
+  const int n = (int)g_timing.size();
+  if (max <= 0) return n;                               // size query: record untouched
+  for (int i = 0; i < n; ++i) {
+    TimingRec& r = g_timing[i];
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+    if (i < max) {
+      if (us) us[i] = ms * 1e3f;
+      if (flops) flops[i] = r.flops;
+      if (kind) kind[i] = r.kind;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_timing.clear();
+  return n;
+}
 
 // how many K splits the 256-tile path uses for an (M, N, K) problem on a 256-CU part
 extern "C" int fvqa_gemm_splits(int M, int N, int K, int dtype) {

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL, EPI_SWIGLU_BWD = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -23,6 +23,8 @@ SIGNATURES = {
     "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "fvqa_gemm_splits": (_i, [_i, _i, _i, _i]),
     "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
+    "fvqa_gemm_timing_enable": (_i, [_i]),
+    "fvqa_gemm_timing_read": (_i, [_i, _p, _p, _p]),
     "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
     "fvqa_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "fvqa_sumres_rmsnorm_fwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),

@@ -114,6 +114,24 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
     return out
 
 
+def gemm_timing_enable(on: bool) -> None:
+    """Measurement probe (include/fvqa.h fvqa_gemm_timing_enable): HIP events around every launch of
+    the 256x256 GEMM kernel on its launch stream, under whichever schedule is running."""
+    _lib.check(_lib.load().fvqa_gemm_timing_enable(1 if on else 0), "fvqa_gemm_timing_enable")
+
+
+def gemm_timing_read():
+    """-> list of (microseconds, flops, kind) per recorded launch; clears the record."""
+    import ctypes as C
+    lib = _lib.load()
+    n = int(lib.fvqa_gemm_timing_read(0, None, None, None))
+    if n <= 0:
+        return []
+    us, fl, kd = (C.c_float * n)(), (C.c_double * n)(), (C.c_int * n)()
+    got = int(lib.fvqa_gemm_timing_read(n, C.cast(us, C.c_void_p), C.cast(fl, C.c_void_p), C.cast(kd, C.c_void_p)))
+    return [(float(us[i]), float(fl[i]), int(kd[i])) for i in range(min(n, got))]
+
+
 def gemm_nt_partial(a: torch.Tensor, b: torch.Tensor):
     """a[M,K] @ b[N,K]^T left as fp32 split-K partial sums: returns (ws, splits) with ws a
     (splits, M, N) fp32 view of the shared GEMM workspace, to be consumed by sumres_rmsnorm_fwd /

@@ -66,6 +66,14 @@ int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* ta
  * ([splits][M][N]) it then needs; a too-small/NULL workspace silently falls back to 1 split. */
 int fvqa_gemm_splits(int M, int N, int K, int dtype);
 size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
+/* Measurement probe (bench.py roofline; no reference counterpart): while enabled, every launch of the
+ * 256x256 GEMM kernel is bracketed by HIP events on ITS launch stream (the kernel only — fix-up
+ * passes are outside the pair). fvqa_gemm_timing_read synchronises, returns the number of launches
+ * recorded since enable and fills up to `max` entries: duration (us), algorithmic FLOPs (2*M*N*K of
+ * that launch) and kind = epilogue | split_k << 4 | out_is_f32 << 5 | in_is_f32 << 6; it then clears
+ * the record (max <= 0: size query only, nothing cleared). enable(0) stops recording. Not thread-safe; one measuring host thread. */
+int fvqa_gemm_timing_enable(int on);
+int fvqa_gemm_timing_read(int max, float* us, double* flops, int* kind);
 
 /* ---- RMSNorm (llama/model.py:37-42; used :185,186,347) -------------------------------- */
 int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int dim,

@@ -48,3 +48,39 @@ for name, M, N, K in SHAPES:
         cells.append(f"{t:8.1f} {2.0 * M * N * K / t / 1e6:7.0f} {err:8.1e} s{sp}")
     print(f"{name:10s} {M:5d} {N:6d} {K:6d} " + "  ".join(cells), flush=True)
 print("sum per layer-equivalent (us):", {v: round(t, 1) for v, t in tot.items()})
+
+if os.environ.get("GB_STEP", "1") == "1":
+    # the launches of one 7B layer exactly as the step issues them (split-K outputs left as fp32
+    # partials for the fused norm kernels, SwiGLU' epilogue on w2t, tail plan on w13)
+    print("\n-- one layer as the step issues it --")
+    layer = [("qkv_fwd", "plain"), ("wo_fwd", "partial"), ("w13_fwd", "plain"), ("w2_fwd", "partial"),
+             ("w2t_bwd", "swiglu"), ("w13t_bwd", "partial"), ("wot_bwd", "partial"), ("qkvt_bwd", "partial")]
+    shp = {n: (M, N, K) for n, M, N, K in SHAPES}
+    tot_t = tot_f = 0.0
+    for name, kind in layer:
+        M, N, K = shp[name]
+        a = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
+        b = ((torch.rand(N, K, device=dev) * 2 - 1) / K ** 0.5).bfloat16()
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        if kind == "swiglu":
+            ab = (torch.rand(M, 2 * N, device=dev) * 2 - 1).bfloat16()
+            dab = torch.empty_like(ab)
+        ts = []
+        for r in range(ROUNDS + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if kind == "plain":
+                ops.gemm_nt(a, b, out)
+            elif kind == "partial":
+                ops.gemm_nt_partial(a, b)
+            else:
+                ops.gemm_nt_swiglu_bwd(a, b, ab, dab)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                ts.append(e0.elapsed_time(e1) * 1e3)
+        t = sorted(ts)[len(ts) // 2]
+        tot_t += t
+        tot_f += 2.0 * M * N * K
+        print(f"{name:10s} {kind:8s} {t:8.1f} us {2.0 * M * N * K / t / 1e6:7.0f} TF/s", flush=True)
+    print(f"layer total {tot_t:.1f} us, {tot_f / tot_t / 1e6:.0f} TF/s")

@@ -212,7 +212,8 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
 // variant: 0 = auto (256x256 ring kernel with automatic split-K when the problem is large enough,
 // else the 128x128 kernel); 1 = 128x128 register-staged; 2 = 128x128 LDS-DMA; 3 = 256x256 default
 // loop; 4 = 256x256 plain 64-byte-row ring loop;
-// 7 = 256x256 wide-row (128-byte) two-stage ring; 8 = wide-row asymmetric rings (A x2, B x3, role-split DMA); 9 = the same with waves 4-7 staggered by half a stage;
+// 7 = 256x256 wide-row (128-byte) two-stage ring; 8 = wide-row asymmetric rings (A x2, B x3, role-split DMA); 9 = the same with waves 4-7 staggered by half a stage (the default loop, tile width chosen per problem);
+// 10 / 11 = the default loop with the tile forced 192 / 256 columns wide;
 // 16+s = 256x256 default loop with exactly s K-splits (tests / tuning).
 extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail, int M, int N,
                             int K, int lda, int ldb, int ldc, int m_split, int dtype, int out_dtype, int epilogue,
@@ -233,9 +234,9 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
     return FVQA_EALIGN;
   if (lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
-  const bool big = epilogue == FVQA_EPI_PARTIAL || epilogue == FVQA_EPI_SWIGLU_BWD || (variant >= 3 && variant <= 9 && variant != 5 && variant != 6) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
+  const bool big = epilogue == FVQA_EPI_PARTIAL || epilogue == FVQA_EPI_SWIGLU_BWD || (variant >= 3 && variant <= 11 && variant != 5 && variant != 6) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
   if (big) {
-    const int mode = variant == 4 ? 0 : variant == 7 ? 2 : variant == 8 ? 3 : variant == 9 ? 6 : FVQA_GEMM256_DEFAULT_MODE;
+    const int mode = variant == 4 ? 0 : variant == 7 ? 2 : variant == 8 ? 3 : variant == 9 ? 6 : variant == 10 ? 63 : variant == 11 ? 61 : FVQA_GEMM256_DEFAULT_MODE;
     return fvqa_gemm_nt_256_impl(A, B, C, R, tail, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, m_split, dtype,
                                  out_dtype, epilogue, variant >= 16 ? variant - 16 : 0, mode, st);
   }

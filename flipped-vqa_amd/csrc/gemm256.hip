@@ -87,7 +87,8 @@ __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
 // PIPE (loop structure): 0 = 64-byte rows, symmetric 4-slot ring (kept for ablation);
 //       2 = 128-byte rows, 2-slot ring; 3 = 128-byte rows, asymmetric A/B rings with role-split DMA;
 //       6 = 3 plus the half-stage stagger of waves 4-7 (default).
-template <typename T, typename TO, int EPI, bool SPLIT, int PIPE>
+// NT: 16-column MFMA blocks per wave along N (4 -> 256-wide tile; 3 -> 192-wide, PIPE 6 only).
+template <typename T, typename TO, int EPI, bool SPLIT, int PIPE, int NT = 4>
 __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, const T* __restrict__ B,
                                                    TO* __restrict__ C, const T* __restrict__ R,
                                                    float* __restrict__ tail, float* __restrict__ ws, int M, int N,
@@ -102,10 +103,12 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
   const int tmi = wid % tiles_m;
   const int sp = (wid / tiles_m) % splits;
   const int tni = wid / (tiles_m * splits);
+  static_assert(NT == 4 || (NT == 3 && PIPE == 6), "192-wide tiles exist for the default loop only");
+  constexpr int WN = 16 * NT;              // output columns per wave
 #if defined(FVQA_ABLATE) && (FVQA_ABLATE & 32)
   const int m0 = 0, n0 = 0;      // timing experiment: every workgroup streams the same (L2-resident) tiles
 #else
-  const int m0 = tmi * TM, n0 = tni * TN;
+  const int m0 = tmi * TM, n0 = tni * (4 * WN);
 #endif
   const int nk_all = K / KE;
   // K range of this split in stages; the wide-row loop eats stages in pairs, so its ranges are even
@@ -151,11 +154,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
   };
   auto issue = [&](int st) { issue_slot(st, st & (NSTAGE - 1)); };
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NT];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read: row (lane&15) of each 16-row block, 16-byte chunk (lane>>4), swizzled
   const int frow = lane & 15;
@@ -168,7 +171,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
   // LDS load wait for ALL in-flight LDS-DMA (s_waitcnt vmcnt(0)), which would drain the ring each
   // stage. The reads return in issue order, so counted lgkmcnt waits release the MFMAs; each wait
   // statement names the registers it guards ("+v") so no consumer is scheduled above it.
+#if defined(FVQA_ABLATE) && (FVQA_ABLATE & 4)
+#define FVQA_DSR(dst, addr, off) dst = u32x4{(unsigned)(addr), (unsigned)(off), 0x3f803f80u, 0x3f803f80u}
+#else
 #define FVQA_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#endif
 #define FVQA_READ12(A_, B_, slot)                                                                          \
   {                                                                                                          \
     const unsigned sb_ = lds0 + (unsigned)((slot) * STAGE);                                                  \
@@ -197,14 +204,17 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     // vmcnt retires in order per wave, so the two streams are issued by DIFFERENT waves: waves 0-3
     // move A and wait vmcnt(0) for stage u; waves 4-7 move B two stages ahead and wait with one
     // newer stage (8 loads) still in flight. One barrier per stage publishes both.
-    constexpr int WROW = 128, WOP = TM * WROW;            // 32 KiB per operand per stage
+    constexpr int WROW = 128, WOP = TM * WROW;            // A: 32 KiB per stage
+    constexpr int WOPB = 4 * WN * WROW;                   // B: 32 KiB (NT 4) / 24 KiB (NT 3) per stage
+    constexpr int NPB = 2 * NT;                           // 1-KiB pieces per B wave per stage
     const int nw = nk / 2;
     const bool bwave = w >= 4;                            // wave-uniform DMA role
     const int wq = w & 3;
     const T* wsrc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int piece = wq * 8 + t;                       // 32 pieces of 8 rows x 128 B per operand
+      // pieces of 8 rows x 128 B: 32 per A stage (8 per wave), 8*NT per B stage (NPB per wave)
+      const int piece = bwave ? wq * NPB + (t < NPB ? t : NPB - 1) : wq * 8 + t;
       const int row = piece * 8 + (lane >> 3);
       const int c = (lane & 7) ^ (row & 7);
       int ga = m0 + row; ga = ga < M ? ga : M - 1;
@@ -216,48 +226,66 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     char* const ringB = smem + 2 * WOP;                   // 3 slots
     // piece q (0..7) of this wave's operand for stage u; slot = ring slot of that stage
     auto issue_piece = [&](int u, int slot, int q) {
-      char* d = (bwave ? ringB : ringA) + slot * WOP + (wq * 8 + q) * 1024;
+      char* d = bwave ? ringB + slot * WOPB + (wq * NPB + q) * 1024 : ringA + slot * WOP + (wq * 8 + q) * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[q] + (size_t)u * 2 * KE),
                                        (__attribute__((address_space(3))) void*)d, 16, 0, 0);
     };
     const int fsw = lane & 7, fkc = lane >> 4;
     const unsigned rowA = (unsigned)((wr * 128 + frow) * WROW);
-    const unsigned rowB = (unsigned)(2 * WOP + (wc * 64 + frow) * WROW);
+    const unsigned rowB = (unsigned)(2 * WOP + (wc * WN + frow) * WROW);
     const unsigned ck0 = (unsigned)(((0 + fkc) ^ fsw) << 4), ck1 = (unsigned)(((4 + fkc) ^ fsw) << 4);
 #define FVQA_WREAD(A_, B_, pa0, pb0, ck)                                                                     \
   {                                                                                                          \
     const unsigned pa_ = (pa0) + (ck), pb_ = (pb0) + (ck);                                                   \
-    FVQA_DSR(B_[0], pb_, 0);    FVQA_DSR(B_[1], pb_, 2048);  FVQA_DSR(B_[2], pb_, 4096);  FVQA_DSR(B_[3], pb_, 6144);  \
+    FVQA_DSR(B_[0], pb_, 0);    FVQA_DSR(B_[1], pb_, 2048);  FVQA_DSR(B_[2], pb_, 4096);                               \
+    if constexpr (NT == 4) FVQA_DSR(B_[3], pb_, 6144);                                                       \
     FVQA_DSR(A_[0], pa_, 0);    FVQA_DSR(A_[1], pa_, 2048);  FVQA_DSR(A_[2], pa_, 4096);  FVQA_DSR(A_[3], pa_, 6144);  \
     FVQA_DSR(A_[4], pa_, 8192); FVQA_DSR(A_[5], pa_, 10240); FVQA_DSR(A_[6], pa_, 12288); FVQA_DSR(A_[7], pa_, 14336); \
   }
 #if defined(FVQA_ABLATE) && (FVQA_ABLATE & 1)
 #define FVQA_WROW(i, n)                                                                \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
-  asm volatile("" ::"v"(a[i]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));            \
+  asm volatile("" ::"v"(a[i]), "v"(b[0]), "v"(b[1]), "v"(b[2]));                       \
   __builtin_amdgcn_sched_barrier(0);
 #else
 #define FVQA_WROW(i, n)                                                                \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a[i]));                              \
   Mma256<T>::run(a[i], b[0], acc[i][0]); Mma256<T>::run(a[i], b[1], acc[i][1]);        \
-  Mma256<T>::run(a[i], b[2], acc[i][2]); Mma256<T>::run(a[i], b[3], acc[i][3]);        \
+  Mma256<T>::run(a[i], b[2], acc[i][2]);                                               \
+  if constexpr (NT == 4) Mma256<T>::run(a[i], b[3], acc[i][NT - 1]);                   \
   __builtin_amdgcn_sched_barrier(0);
 #endif
 #if defined(FVQA_ABLATE) && (FVQA_ABLATE & 2)
 #define FVQA_WROW_DMA(i, n, q) FVQA_WROW(i, n)
 #else
+#if defined(FVQA_AEARLY) && FVQA_AEARLY == 1
 #define FVQA_WROW_DMA(i, n, q)                                                         \
   FVQA_WROW(i, n)                                                                      \
-  if (more) issue_piece(nu, nslot, q);                                                 \
+  if (more) {                                                                          \
+    if (bwave) { if (q < NPB) issue_piece(nu, nslot, q); }                             \
+    else if (q < 4) { issue_piece(nu, nslot, 2 * q); issue_piece(nu, nslot, 2 * q + 1); } \
+  }                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
+#elif defined(FVQA_AEARLY) && FVQA_AEARLY == 2
+#define FVQA_WROW_DMA(i, n, q)                                                         \
+  FVQA_WROW(i, n)                                                                      \
+  if (more && bwave && q < NPB) issue_piece(nu, nslot, q);                             \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define FVQA_WROW_DMA(i, n, q)                                                         \
+  FVQA_WROW(i, n)                                                                      \
+  if (more && (!bwave || q < NPB)) issue_piece(nu, nslot, q);                          \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
     // prologue: A stage 0; B stages 0 and 1
     if (nw > 0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) issue_piece(0, 0, q);
+      for (int q = 0; q < 8; ++q)
+        if (!bwave || q < NPB) issue_piece(0, 0, q);
       if (bwave && nw > 1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) issue_piece(1, 1, q);
+        for (int q = 0; q < NPB; ++q) issue_piece(1, 1, q);
       }
     }
     int sa = 0, sbs = 0;                                  // ring slots of stage u: u % 2, u % 3
@@ -267,12 +295,17 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     u32x4 hl[4], hb[4];
 #define FVQA_HROW(i)                                                                   \
   Mma256<T>::run(hl[i], hb[0], acc[i][0]); Mma256<T>::run(hl[i], hb[1], acc[i][1]);    \
-  Mma256<T>::run(hl[i], hb[2], acc[i][2]); Mma256<T>::run(hl[i], hb[3], acc[i][3]);
+  Mma256<T>::run(hl[i], hb[2], acc[i][2]);                                             \
+  if constexpr (NT == 4) Mma256<T>::run(hl[i], hb[3], acc[i][NT - 1]);
 #define FVQA_UROW(i)                                                                   \
   Mma256<T>::run(au[i - 4], hb[0], acc[i][0]); Mma256<T>::run(au[i - 4], hb[1], acc[i][1]); \
-  Mma256<T>::run(au[i - 4], hb[2], acc[i][2]); Mma256<T>::run(au[i - 4], hb[3], acc[i][3]);
+  Mma256<T>::run(au[i - 4], hb[2], acc[i][2]);                                              \
+  if constexpr (NT == 4) Mma256<T>::run(au[i - 4], hb[3], acc[i][NT - 1]);
     for (int u = 0; u < nw; ++u) {
-      if (bwave && u + 1 < nw) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // B(u) landed, B(u+1) in flight
+      if (bwave && u + 1 < nw) {                          // B(u) landed, B(u+1) (NPB loads) in flight
+        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                       // stage u published; slots of stage u-1 are free
       asm volatile("" ::: "memory");
@@ -280,7 +313,14 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
       const int nslot = bwave ? (sbs == 0 ? 2 : sbs - 1) : (sa ^ 1);
       const bool more = nu < nw;
       const unsigned pa0 = lds0 + (unsigned)(sa * WOP) + rowA;
-      const unsigned pb0 = lds0 + (unsigned)(sbs * WOP) + rowB;
+      const unsigned pb0 = lds0 + (unsigned)(sbs * WOPB) + rowB;
+#if defined(FVQA_AEARLY) && FVQA_AEARLY == 2
+      if (more && !bwave) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_piece(nu, nslot, q);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       if (late && u > 0) {                                // deferred rows 0-63 of stage u-1, k-step 1
         FVQA_HROW(0) FVQA_HROW(1) FVQA_HROW(2) FVQA_HROW(3)
         __builtin_amdgcn_sched_barrier(0);
@@ -288,19 +328,21 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
       {
         u32x4 a[8], b[4];
         FVQA_WREAD(a, b, pa0, pb0, ck0);
-        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+        if constexpr (NT == 4) asm volatile("" : "+v"(b[3]));
         FVQA_WROW_DMA(0, 7, 0) FVQA_WROW_DMA(1, 6, 1) FVQA_WROW_DMA(2, 5, 2) FVQA_WROW_DMA(3, 4, 3)
         FVQA_WROW_DMA(4, 3, 4) FVQA_WROW_DMA(5, 2, 5) FVQA_WROW_DMA(6, 1, 6) FVQA_WROW_DMA(7, 0, 7)
       }
       {
         u32x4 au[4];
         const unsigned pa_ = pa0 + ck1, pb_ = pb0 + ck1;
-        FVQA_DSR(hb[0], pb_, 0);    FVQA_DSR(hb[1], pb_, 2048);  FVQA_DSR(hb[2], pb_, 4096);  FVQA_DSR(hb[3], pb_, 6144);
+        FVQA_DSR(hb[0], pb_, 0);    FVQA_DSR(hb[1], pb_, 2048);  FVQA_DSR(hb[2], pb_, 4096);
+        if constexpr (NT == 4) FVQA_DSR(hb[3], pb_, 6144);
         FVQA_DSR(au[0], pa_, 8192); FVQA_DSR(au[1], pa_, 10240); FVQA_DSR(au[2], pa_, 12288); FVQA_DSR(au[3], pa_, 14336);
         FVQA_DSR(hl[0], pa_, 0);    FVQA_DSR(hl[1], pa_, 2048);  FVQA_DSR(hl[2], pa_, 4096);  FVQA_DSR(hl[3], pa_, 6144);
         asm volatile("s_waitcnt lgkmcnt(4)"
-                     : "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(hb[3]), "+v"(au[0]), "+v"(au[1]), "+v"(au[2]),
-                       "+v"(au[3]));
+                     : "+v"(hb[0]), "+v"(hb[1]), "+v"(hb[2]), "+v"(au[0]), "+v"(au[1]), "+v"(au[2]), "+v"(au[3]));
+        if constexpr (NT == 4) asm volatile("" : "+v"(hb[3]));
         FVQA_UROW(4) FVQA_UROW(5) FVQA_UROW(6) FVQA_UROW(7)
         __builtin_amdgcn_sched_barrier(0);
         // retire the reads of rows 0-63 before the next barrier (their slot may be refilled after it)
@@ -571,7 +613,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      for (int j = 0; j < NT; ++j) s_ += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s_ == 1.2345678e-30f) ws[0] = s_;
     return;
   }
@@ -593,7 +635,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     const int q = lane >> 3, k = lane & 7;
     const int rl = W4 ? ((q & 1) * 8 + (q >> 1)) : q;  // row of this lane inside an 8-row group set
     const int cA = W4 ? k : 2 * k, cB = W4 ? 8 + k : 2 * k + 1;
-    const int nA = n0 + wc * 64 + cA * 4, nB = n0 + wc * 64 + cB * 4;
+    const bool okA = cA < 4 * NT, okB = cB < 4 * NT;      // a 192-wide tile leaves chunks 12..15 of the row unused
+    const int nA = okA ? n0 + wc * WN + cA * 4 : N, nB = okB ? n0 + wc * WN + cB * 4 : N;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int mb = m0 + wr * 128 + p * 64;
@@ -618,7 +661,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NT; ++j)
           *reinterpret_cast<f32x4*>(stg + (ii * 16 + crow) * 64 + (((j * 4 + (lane >> 4)) ^ crow) << 2)) =
               acc[p * 4 + ii][j];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -702,8 +745,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     const int m = m0 + wr * 128 + i * 16 + crow;
     if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wc * 64 + j * 16 + ccol;
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wc * WN + j * 16 + ccol;
       if (n >= N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (vec_ok) {                    // n % 4 == 0 and N % 4 == 0: the four columns are all inside
@@ -815,16 +858,17 @@ struct TimingScope {
   }
 };
 
-template <typename T, typename TO, int EPI, int PIPE>
+template <typename T, typename TO, int EPI, int PIPE, int NT = 4>
 int launch_256(const void* A, const void* B, void* C, const void* R, float* tail, float* ws, int M, int N, int K,
                int lda, int ldb, int ldc, int m_split, int splits, bool partial_only, hipStream_t st) {
-  const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
+  constexpr int TNW = 64 * NT;
+  const int tm = (M + TM - 1) / TM, tn = (N + TNW - 1) / TNW;
   dim3 grid(tm * tn * splits), block(512);
   constexpr int RING = ((PIPE == 3 || PIPE == 6) ? 5 : PIPE == 2 ? 4 : PIPE == 0 ? NSTAGE : PIPE) * STAGE;
   constexpr int STG = 8 * 64 * 64 * 4;                  // epilogue staging: 8 waves x 64 rows x 64 floats
   constexpr int LDSB = RING > STG ? RING : STG;
   if (splits > 1 || partial_only) {
-    auto k = gemm_nt_256<T, TO, EPI, true, PIPE>;
+    auto k = gemm_nt_256<T, TO, EPI, true, PIPE, NT>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
     {
@@ -840,7 +884,7 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
                          (const T*)R, tail, M, N, ldc, m_split, splits);
     }
   } else {
-    auto k = gemm_nt_256<T, TO, EPI, false, PIPE>;
+    auto k = gemm_nt_256<T, TO, EPI, false, PIPE, NT>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
     TimingScope ts(st, 2.0 * M * N * K, EPI | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
@@ -921,20 +965,49 @@ extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
   return p.sr > 1 ? (size_t)p.sr * M * (N - p.n1) * sizeof(float) : 0;
 }
 
-// mode: 0 = plain ring loop, 4 / 5 = software-pipelined loop over a 4- / 5-deep ring
+// Tile width for an unsplit problem on 256 CUs: rounds x work per tile, 256-wide (with its tail-round
+// plan where that applies: + 1/sr round + a fix-up pass) against 192-wide tiles at 3/4 of the work.
+// M = 1024: W2^T (N = 11008) 172 x 1.0 -> 232 x 0.75; W1|W3 (N = 22016) 1.5 rounds + fix-up -> 2 x 0.75.
+static int pick_nt(int M, int N, int K, int dtype, bool tail_plan_ok) {
+  const int tm = (M + TM - 1) / TM;
+  const int t256 = tm * ((N + 255) / 256), t192 = tm * ((N + 191) / 192);
+  double c256 = (double)((t256 + 255) / 256);
+  if (tail_plan_ok) {
+    const TailPlan p = tail_plan(M, N, K, dtype);
+    if (p.sr > 1) c256 = (double)(p.n1 / TN * tm / 256) + 1.0 / p.sr + 0.1;
+  }
+  // measured (profiles/r01_gemm_ablation_tilewidth.log): at equal rounds the narrower tile buys nothing —
+  // the loop is bound by LDS/DMA traffic per stage, which shrinks 9 %, not by MFMA work, which shrinks 25 %
+  const double c192 = 0.95 * (double)((t192 + 255) / 256);
+  return c192 < c256 - 0.2 ? 3 : 4;
+}
+
+// mode: PIPE of the kernel loop (0, 2, 3, 6); 61 / 63 = PIPE 6 with the tile width forced to 256 / 192
 int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, float* tail, void* ws,
                           size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
                           int out_dtype, int epilogue, int force_splits, int mode, hipStream_t st) {
+  int force_nt = 0;
+  if (mode == 61) { force_nt = 4; mode = 6; }
+  if (mode == 63) { force_nt = 3; mode = 6; }
   if (epilogue == FVQA_EPI_SWIGLU_BWD) {       // elementwise epilogue on whole outputs: no K split
+    const int nt = force_nt ? force_nt : pick_nt(M, N, K, dtype, false);
     if (dtype == FVQA_BF16)
-      return launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda, ldb,
-                                                               ldc, m_split, 1, false, st);
-    return launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda, ldb, ldc,
-                                                           m_split, 1, false, st);
+      return nt == 3 ? launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6, 3>(A, B, C, R, nullptr, (float*)ws, M, N, K,
+                                                                            lda, ldb, ldc, m_split, 1, false, st)
+                     : launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K,
+                                                                         lda, ldb, ldc, m_split, 1, false, st);
+    return nt == 3 ? launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6, 3>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda,
+                                                                        ldb, ldc, m_split, 1, false, st)
+                   : launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda,
+                                                                     ldb, ldc, m_split, 1, false, st);
   }
   int splits = force_splits > 0 ? force_splits : fvqa_gemm_splits(M, N, K, dtype);
   const bool partial = epilogue == FVQA_EPI_PARTIAL;
-  if (!partial && force_splits == 0 && splits == 1 && tail == nullptr && ws != nullptr) {
+  const bool plan_ok = !partial && force_splits == 0 && splits == 1 && tail == nullptr && ws != nullptr;
+  int nt = 4;
+  if (mode == 6 && !partial && splits == 1 && tail == nullptr)
+    nt = force_nt ? force_nt : (force_splits == 0 ? pick_nt(M, N, K, dtype, plan_ok) : 4);
+  if (plan_ok && nt == 4) {
     const TailPlan p = tail_plan(M, N, K, dtype);
     if (p.sr > 1 && ws_bytes >= (size_t)p.sr * M * (N - p.n1) * sizeof(float)) {
       const size_t eo = out_dtype == FVQA_F32 ? 4 : fvqa_dtype_size(dtype), ei = fvqa_dtype_size(dtype);
@@ -951,16 +1024,18 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
   } else if (splits > 1 && (!ws || ws_bytes < (size_t)splits * M * N * sizeof(float) || (N & 3))) {
     splits = 1;
   }
-#define GO2(T, TO, P)                                                                                          \
+#define GO3(T, TO, P, NTV)                                                                                     \
   return epilogue == FVQA_EPI_RESIDUAL                                                                         \
-             ? launch_256<T, TO, FVQA_EPI_RESIDUAL, P>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc,    \
-                                                       m_split, splits, false, st)                             \
-             : launch_256<T, TO, FVQA_EPI_NONE, P>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc,        \
-                                                   m_split, splits, partial, st)
-#define GO(T, TO)                     \
-  if (mode == 2) { GO2(T, TO, 2); }   \
-  if (mode == 3) { GO2(T, TO, 3); }   \
-  if (mode == 6) { GO2(T, TO, 6); }   \
+             ? launch_256<T, TO, FVQA_EPI_RESIDUAL, P, NTV>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb,    \
+                                                            ldc, m_split, splits, false, st)                   \
+             : launch_256<T, TO, FVQA_EPI_NONE, P, NTV>(A, B, C, R, tail, (float*)ws, M, N, K, lda, ldb, ldc,   \
+                                                        m_split, splits, partial, st)
+#define GO2(T, TO, P) GO3(T, TO, P, 4)
+#define GO(T, TO)                                 \
+  if (mode == 2) { GO2(T, TO, 2); }               \
+  if (mode == 3) { GO2(T, TO, 3); }               \
+  if (mode == 6 && nt == 3) { GO3(T, TO, 6, 3); } \
+  if (mode == 6) { GO2(T, TO, 6); }               \
   GO2(T, TO, 0)
   if (dtype == FVQA_BF16) {
     if (out_dtype == FVQA_F32) { GO(bf16_t, float); }
@@ -969,4 +1044,5 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
   GO(float, float);
 #undef GO
 #undef GO2
+#undef GO3
 }

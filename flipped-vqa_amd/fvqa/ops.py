@@ -94,7 +94,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
     code = dt_code(a.dtype)
     if variant >= 16:
         need = (variant - 16) * M * N * 4 if variant > 17 else 0
-    elif variant in (0, 3, 4, 7, 8, 9):
+    elif variant in (0, 3, 4, 7, 8, 9, 10, 11):
         need = int(lib.fvqa_gemm_workspace(M, N, K, code))
     else:
         need = 0

@@ -51,10 +51,10 @@ def test_gemm_nt(dtype, variant, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [3, 4, 7, 8, 9, 17, 18, 19, 20])   # 256x256 ring kernel: loops / 1..4 K-splits
+@pytest.mark.parametrize("variant", [3, 4, 7, 8, 9, 10, 11, 17, 18, 19, 20])   # 256-row ring kernel: loops / tile widths / 1..4 K-splits
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1034, 512, 1024), (300, 768, 2112), (1024, 4096, 4096)])
 def test_gemm_nt_256_ring_and_splitk(dtype, variant, M, N, K):
-    if (M, N, K) == (1024, 4096, 4096) and dtype == torch.float32 and variant not in (3, 9, 20):
+    if (M, N, K) == (1024, 4096, 4096) and dtype == torch.float32 and variant not in (3, 9, 10, 20):
         pytest.skip("fp32 big shape covered by two variants")
     a, b = rnd(M, K, dtype=dtype, seed=11), rnd(N, K, dtype=dtype, scale=1 / math.sqrt(K), seed=12)
     r = rnd(M, N, dtype=dtype, seed=13)
@@ -85,6 +85,26 @@ def test_gemm_nt_swiglu_bwd_epilogue(dtype, M, Hf, D):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1024, 2752, 1024), (522, 200, 256), (256, 192, 128), (1034, 1160, 512)])
+def test_gemm_nt_192_wide_tiles(dtype, M, N, K):
+    """The 192-column tile (W2^T / W1|W3 shapes at reduced size, N not a multiple of 192 or of 64, ragged
+    M): forced (variant 10) against the forced 256-wide tile (variant 11) and the fp64 product; bf16 and
+    fp32 outputs, residual epilogue."""
+    a, b = rnd(M, K, dtype=dtype, seed=51), rnd(N, K, dtype=dtype, scale=1 / math.sqrt(K), seed=52)
+    r = rnd(M, N, dtype=dtype, seed=53)
+    ref = a.double() @ b.double().T
+    o192 = torch.empty(M, N, dtype=dtype, device=DEV)
+    o256 = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), o192, residual=dev(r), variant=10)
+    ops.gemm_nt(dev(a), dev(b), o256, residual=dev(r), variant=11)
+    assert rel(o192, ref + r.double()) < tol(dtype, 5e-5, 1e-2)
+    assert torch.equal(o192, o256)                     # same k order per output: bitwise equal
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), o32, variant=10)
+    assert rel(o32, ref) < tol(dtype, 5e-5, 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_nt_tail_round_plan(dtype):
     """More tiles than CUs with a partly filled last round: the last N-tile columns run as a second,
     K-split launch (W1|W3-shaped problem, reduced K)."""
@@ -104,7 +124,7 @@ def test_gemm_nt_identity_asymmetric(dtype):
     M = N = K = 128
     a = torch.eye(M, K, dtype=dtype)
     b = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 0.5).to(dtype)     # exactly representable
-    for variant in (2, 3, 4, 7, 8, 9, 18):
+    for variant in (2, 3, 4, 7, 8, 9, 10, 11, 18):
         out = torch.empty(M, N, dtype=torch.float32, device=DEV)
         ops.gemm_nt(dev(a), dev(b), out, variant=variant)
         assert torch.equal(out.cpu(), b.float().T.contiguous()), variant

@@ -472,30 +472,38 @@ inline int check_dims(int n_seq, int S, int H, int head_dim, int A, int F) {
 }  // namespace
 
 // bf16 production build on the matrix cores (attn_mfma.hip); FVQA_ATTN_VALU=1 keeps the vector build
+int fvqa_attn_mfma_qblocks(int S);
 int fvqa_attn_fwd_mfma(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1, const float* gate2,
-                       const int32_t* vstart, int n_seq, int S, int H, int A, int F, hipStream_t st);
+                       const int32_t* vstart, const float* cos_t, const float* sin_t, int n_seq, int S, int H, int A,
+                       int F, hipStream_t st);
 int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const float* lse_a, const float* lse_t,
-                       const float* gate1, const float* gate2, const int32_t* vstart, void* dqkv, float* delta_a,
-                       float* delta_t, float* gate_part, float* dka, float* dva, int n_seq, int S, int H, int A, int F,
-                       hipStream_t st);
+                       const float* gate1, const float* gate2, const int32_t* vstart, const float* cos_t,
+                       const float* sin_t, void* dqkv, float* delta_a, float* delta_t, float* gate_part, float* dka,
+                       float* dva, int n_seq, int S, int H, int A, int F, hipStream_t st);
 static bool use_mfma_attention() {
   static const bool v = [] { const char* e = getenv("FVQA_ATTN_VALU"); return !(e && e[0] == '1'); }();
   return v;
 }
 
+// 1 when fvqa_attn_fwd/bwd of this dtype apply RoPE themselves (cos_t/sin_t arguments): the bf16 MFMA build
+extern "C" int fvqa_attn_rope_fused(int dtype) { return dtype == FVQA_BF16 && use_mfma_attention() ? 1 : 0; }
+
 extern "C" int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1,
-                             const float* gate2, const int32_t* vstart, int n_seq, int seq_len, int n_heads,
-                             int head_dim, int adapter_len, int max_feats, int dtype, void* stream) {
+                             const float* gate2, const int32_t* vstart, const float* cos_t, const float* sin_t,
+                             int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
+                             int dtype, void* stream) {
   if (!qkv || !o || !lse_a || !lse_t || !gate1 || !gate2 || !vstart) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
+  if ((cos_t == nullptr) != (sin_t == nullptr)) return FVQA_EINVAL;
+  if (cos_t && !fvqa_attn_rope_fused(dtype)) return FVQA_EINVAL;      // the vector build takes rotated q,k only
   int rc = check_dims(n_seq, seq_len, n_heads, head_dim, adapter_len, max_feats);
   if (rc) return rc;
   const int nqb = (seq_len + TILE - 1) / TILE;
   dim3 grid(nqb, n_heads, n_seq), block(256);
   const size_t lds = (size_t)(2 * TILE + 2 * adapter_len) * DH * sizeof(float);
   if (dtype == FVQA_BF16 && use_mfma_attention()) {
-    fvqa_attn_fwd_mfma(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, seq_len, n_heads, adapter_len, max_feats,
-                       (hipStream_t)stream);
+    fvqa_attn_fwd_mfma(qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, n_seq, seq_len, n_heads, adapter_len,
+                       max_feats, (hipStream_t)stream);
     FVQA_CHECK_LAUNCH();
     return FVQA_OK;
   }
@@ -516,9 +524,11 @@ extern "C" size_t fvqa_attn_bwd_workspace(int n_seq, int seq_len, int n_heads, i
 
 extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, const float* lse_a,
                              const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
-                             void* dqkv, float* dgate1, float* dgate2, void* workspace, size_t workspace_bytes,
-                             int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
-                             int dtype, void* stream) {
+                             const float* cos_t, const float* sin_t, void* dqkv, float* dgate1, float* dgate2,
+                             void* workspace, size_t workspace_bytes, int n_seq, int seq_len, int n_heads,
+                             int head_dim, int adapter_len, int max_feats, int dtype, void* stream) {
+  if ((cos_t == nullptr) != (sin_t == nullptr)) return FVQA_EINVAL;
+  if (cos_t && !fvqa_attn_rope_fused(dtype)) return FVQA_EINVAL;
   if (!d_o || !qkv || !o || !lse_a || !lse_t || !gate1 || !gate2 || !vstart || !dqkv || !dgate1 || !dgate2 ||
       !workspace)
     return FVQA_EINVAL;
@@ -539,10 +549,10 @@ extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, co
   const size_t lds_q = (size_t)(2 * TILE + 2 * adapter_len) * DH * sizeof(float);
   const size_t lds_kv = (size_t)(2 * TILE * DH + 2 * TILE) * sizeof(float);
   if (dtype == FVQA_BF16 && use_mfma_attention()) {
-    fvqa_attn_bwd_mfma(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, delta_a, delta_t, gate_part, dka, dva,
-                       n_seq, seq_len, n_heads, adapter_len, max_feats, st);
+    fvqa_attn_bwd_mfma(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, dqkv, delta_a, delta_t,
+                       gate_part, dka, dva, n_seq, seq_len, n_heads, adapter_len, max_feats, st);
     hipLaunchKernelGGL(attn_bwd_reduce_k<bf16_t>, dim3(64), block, 0, st, dka, dva, gate_part, gate1, (bf16_t*)dqkv,
-                       dgate1, dgate2, n_seq, seq_len, n_heads, adapter_len, nqb);
+                       dgate1, dgate2, n_seq, seq_len, n_heads, adapter_len, fvqa_attn_mfma_qblocks(seq_len));
     FVQA_CHECK_LAUNCH();
     return FVQA_OK;
   }

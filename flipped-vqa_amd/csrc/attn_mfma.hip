@@ -2,21 +2,28 @@
 //
 // Same mathematics as attn.hip (reference llama/model.py:98-126); that file stays the exact-fp32
 // vector-ALU build used for the parity gate. Here every product is a v_mfma_f32_16x16x32_bf16 tile
-// product in the NT form C = A·Bᵀ (both operands contraction-contiguous, 16-byte fragments), fp32
-// accumulation, fp32 softmax:
-//   forward, per (sequence, head, 64-query block), one 16-row tile per wave, 64-key tiles:
-//     S  = Q·Kᵀ           A = Q rows (registers, loaded once)      B = K rows        (LDS, row-major)
-//     O += P·V            A = P (bf16, through a per-wave LDS tile) B = Vᵀ rows       (LDS, transposed
-//                                                                                      while staging)
-//   backward dQ kernel (query blocks):  S, dP = dO·Vᵀ (B = V rows), dQ += dS·K (B = Kᵀ rows)
-//   backward dK/dV kernel (key blocks): Sᵀ = K·Qᵀ and dPᵀ = V·dOᵀ come out of the MFMA already
-//     key-major, so Pᵀ and dSᵀ feed dV += Pᵀ·dO (B = dOᵀ rows) and dK += dSᵀ·Q (B = Qᵀ rows)
-//     through one LDS round trip, no cross-lane transposes.
-// Row statistics use the C/D layout of the 16x16 MFMA (col = lane&15, row = 4*(lane>>4)+reg): a row
-// reduction is four xor-shuffles inside a 16-lane group. LDS tiles are padded (+8 bf16 per row) so
-// the ds_read_b128 fragment reads of a 16-lane group fall on distinct bank slots.
+// product in the NT form D = X·Yᵀ (D rows from X, D columns from Y; both operands contraction-
+// contiguous 16-byte fragments), fp32 accumulation, fp32 softmax.
+//
+// One workgroup = 8 waves = 128 queries (forward, dQ) or 128 keys (dK/dV) of one (sequence, head);
+// a wave owns 16 of them; the other side is staged in 128-row tiles (one tile covers S = 128) and
+// consumed in groups of 32 rows = one MFMA k-step.
+//
+// No LDS round trip for P / dS: the score blocks are produced TRANSPOSED with respect to the product
+// that consumes them, so the C/D registers of two 16-row blocks (lane: column i = lane&15, rows
+// 4g..4g+3 of each block, g = lane>>4) ARE the 8-element operand fragment of the next MFMA, with the
+// contraction index running in the order (4g+r | 16+4g+r). The matching operand is fetched from the
+// row-major LDS tile with ds_read_b64_tr_b16 at exactly those rows (frags_tr_perm):
+//   forward  (wave = 16 queries):  Sᵀ = K·Qᵀ  ->  Oᵀ += Vᵀ·P          (P from registers)
+//   dQ       (wave = 16 queries):  Sᵀ, dPᵀ = V·dOᵀ  ->  dQᵀ += Kᵀ·dS   (dS from registers)
+//   dK/dV    (wave = 16 keys):     S = Q·Kᵀ, dP = dO·Vᵀ -> dVᵀ += dOᵀ·P, dKᵀ += Qᵀ·dS
+// Every output therefore lands as 4 consecutive head dims per lane (8-byte stores), row statistics
+// are per-lane scalars (two xor-shuffles across g), and RoPE fuses for free: the rotation pairs
+// (2i, 2i+1) sit in one lane both in the 16-byte loads (q, k rotated while loading / staging; values
+// identical to the separate RoPE pass: bf16 in, fp32 rotate, bf16 out) and in the dQ / dK stores
+// (conjugate rotation on the fp32 accumulators). cos_t == NULL means q,k arrive already rotated.
 // The adapter prefix (A <= 16 keys, no RoPE, own softmax scaled by tanh(gate1)) is one extra 16-key
-// tile; its key/value gradients are summed over sequences by attn_bwd_reduce_k (attn.hip), exactly
+// block; its key/value gradients are summed over sequences by attn_bwd_reduce_k (attn.hip), exactly
 // as in the vector build: no float atomics, bitwise repeatable.
 #include "common.h"
 #include <stdlib.h>
@@ -26,394 +33,411 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int DH = 128;
-constexpr int QB = 64;                  // rows (queries or keys) per workgroup
-constexpr int KT = 64;                  // rows per staged tile
+constexpr int BQ = 128;                 // queries / keys per workgroup = rows per staged tile
 constexpr int LDR = DH + 8;             // row-major tile leading dim (bf16 elements): 272 B
-constexpr int LDT = KT + 8;             // transposed tile leading dim: 144 B
-constexpr int LDP = KT + 8;             // per-wave P / dS tile leading dim
+constexpr int HP = DH / 2;              // rotation pairs per head
 constexpr float NEG_BIG = -1e30f;
 
-__device__ __forceinline__ f32x4 mma(const uint4& a, const uint4& b, f32x4 acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+// D[4g+r][lane&15] += sum_k X[4g+r][k] * Y[lane&15][k]
+__device__ __forceinline__ f32x4 mma(const uint4& x, const uint4& y, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, x), __builtin_bit_cast(bf16x8_t, y),
                                                  acc, 0, 0, 0);
 }
-__device__ __forceinline__ float group16_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+__device__ __forceinline__ float across_g_max(float v) {      // over the 4 lanes that share lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
 }
-__device__ __forceinline__ float group16_sum(float v) {
+__device__ __forceinline__ float across_g_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+}
+// two C/D blocks (rows 4g+r of row-block 0 and of row-block 1) -> the 8-element operand fragment
+__device__ __forceinline__ uint4 pack_blocks(const float (&a)[4], const float (&b)[4]) {
+  return make_uint4(pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(b[0], b[1]), pack2(b[2], b[3]));
+}
+// RoPE of 8 consecutive head dims (4 pairs) of one row: bf16 in, fp32 rotate, bf16 out (the arithmetic of
+// rope_qk_k in rowops.hip); c4/s4 point at the row's table entries of the first pair. sign = -1: conjugate.
+__device__ __forceinline__ uint4 rope8(const uint4& v, const float* c4, const float* s4) {
+  const float4 c = *reinterpret_cast<const float4*>(c4), s = *reinterpret_cast<const float4*>(s4);
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+  unsigned o[4];
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int p = 0; p < 4; ++p) {
+    const float e = __uint_as_float(w[p] << 16), d = __uint_as_float(w[p] & 0xFFFF0000u);
+    o[p] = pack2(e * cc[p] - d * ss[p], e * ss[p] + d * cc[p]);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// stage `nrows` rows x 128 of a row-major global matrix (row stride ld elements) into sR[nrows][LDR];
-// rows >= row_limit are zero-filled
-__device__ __forceinline__ void stage_rows(bf16_t* sR, const bf16_t* g, size_t ld, int row0, int row_limit,
-                                           int nrows) {
-  for (int idx = threadIdx.x; idx < nrows * 16; idx += 256) {
-    const int r = idx >> 4, c = idx & 15;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < row_limit) v = *reinterpret_cast<const uint4*>(g + (size_t)(row0 + r) * ld + c * 8);
-    *reinterpret_cast<uint4*>(sR + r * LDR + c * 8) = v;
-  }
-}
-// same rows, stored transposed: sT[d][r] (leading dim ldt), r < nrows
-__device__ __forceinline__ void stage_rows_t(bf16_t* sT, int ldt, const bf16_t* g, size_t ld, int row0,
-                                             int row_limit, int nrows) {
-  for (int idx = threadIdx.x; idx < nrows * 16; idx += 256) {
-    const int r = idx % nrows, c = idx / nrows;     // consecutive lanes -> consecutive r: conflict-light stores
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < row_limit) v = *reinterpret_cast<const uint4*>(g + (size_t)(row0 + r) * ld + c * 8);
-    const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
-    unsigned short* dst = reinterpret_cast<unsigned short*>(sT);
+// stage NR rows x 128 of a row-major global matrix (row stride ld elements) into sR[NR][LDR]; rows >= row_limit
+// are zero-filled; ROPE rotates the row with the tables of position (row index)
+template <bool ROPE, int NR>
+__device__ __forceinline__ void stage_tile(bf16_t* sR, const bf16_t* g, size_t ld, int row0, int row_limit,
+                                           const float* cs, const float* sn) {
+  constexpr int PER = (NR * 16 + 511) / 512;
+  uint4 v[PER];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[(c * 8 + i) * ldt + r] = e[i];
+  for (int t = 0; t < PER; ++t) {
+    const int idx = threadIdx.x + t * 512;
+    const int r = idx >> 4, c = idx & 15;
+    v[t] = make_uint4(0, 0, 0, 0);
+    if (idx < NR * 16 && row0 + r < row_limit) v[t] = *reinterpret_cast<const uint4*>(g + (size_t)(row0 + r) * ld + c * 8);
+  }
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int idx = threadIdx.x + t * 512;
+    const int r = idx >> 4, c = idx & 15;
+    if (idx < NR * 16) {
+      if (ROPE && row0 + r < row_limit)
+        v[t] = rope8(v[t], cs + (size_t)(row0 + r) * HP + 4 * c, sn + (size_t)(row0 + r) * HP + 4 * c);
+      *reinterpret_cast<uint4*>(sR + r * LDR + c * 8) = v[t];
+    }
   }
 }
-// A/B fragment of the 16x16x32 MFMA from a row-major LDS tile: row (lane&15), 8 elements at k0+8*(lane>>4)
-__device__ __forceinline__ uint4 frag(const bf16_t* s, int ld, int row0, int k0, int lane) {
-  return *reinterpret_cast<const uint4*>(s + (row0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
+// operand fragment from a row-major LDS tile: row (lane&15) of the 16-row block at row0, 8 elements at k0+8g
+__device__ __forceinline__ uint4 frag(const bf16_t* s, int row0, int k0, int lane) {
+  return *reinterpret_cast<const uint4*>(s + (row0 + (lane & 15)) * LDR + k0 + 8 * (lane >> 4));
 }
-// B fragments taken COLUMN-wise from a row-major LDS tile X[k][n] with the hardware transpose read
-// ds_read_b64_tr_b16: per 16-lane group it reads 4 rows x 16 columns and hands lane i column i (its 4
-// rows in the 4 elements); lane 4q+p of the group supplies the address of row q, columns 4p..4p+3.
-// Two reads (rows 8g..8g+3 and 8g+4..8g+7 of the 32-deep k-step, g = lane>>4) make the 8-element
-// fragment B[k = 8g + j][n = n0 + (lane&15)]. Fills f[d] for the 8 column tiles n0 = 16*d; one wait.
-__device__ __forceinline__ void frags_tr8(const bf16_t* s, int k0, int lane, uint4 (&f)[8]) {
+__device__ __forceinline__ uint4 frag_g(const bf16_t* g, size_t ld, int row, int k0, int lane) {
+  return *reinterpret_cast<const uint4*>(g + (size_t)row * ld + k0 + 8 * (lane >> 4));
+}
+// Operand fragments taken COLUMN-wise from a row-major LDS tile X[row][d] with the hardware transpose read
+// ds_read_b64_tr_b16 (per 16-lane group: 4 rows x 16 columns in, lane i gets column i, its 4 rows in the 4
+// elements; lane 4q+p of the group supplies the address of row q, columns 4p..4p+3). For each of the 8
+// column blocks dt: f[dt] = { X[rb+4g+e][16dt+i] (e=0..3), X[rb+16+4g+e][16dt+i] (e=0..3) } — the k order of
+// pack_blocks. HI = false leaves the second half zero (16-row adapter block).
+template <bool HI>
+__device__ __forceinline__ void frags_tr_perm(const bf16_t* s, int rb, int lane, uint4 (&f)[8]) {
   const int g = lane >> 4, i = lane & 15;
-  const bf16_t* a0 = s + (k0 + 8 * g + (i >> 2)) * LDR + 4 * (i & 3);
+  const bf16_t* a0 = s + (rb + 4 * g + (i >> 2)) * LDR + 4 * (i & 3);
   const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) bf16_t*)a0;
   uint2 lo[8], hi[8];
 #define FVQA_TR(d)                                                                                       \
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[d]) : "v"(addr), "i"(32 * d));            \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d]) : "v"(addr), "i"(32 * d + 8 * LDR));
+  if (HI) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d]) : "v"(addr), "i"(32 * d + 32 * LDR));
   FVQA_TR(0) FVQA_TR(1) FVQA_TR(2) FVQA_TR(3) FVQA_TR(4) FVQA_TR(5) FVQA_TR(6) FVQA_TR(7)
 #undef FVQA_TR
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
-                 "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+  if (HI) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                   "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
 #pragma unroll
-  for (int d = 0; d < 8; ++d) f[d] = make_uint4(lo[d].x, lo[d].y, hi[d].x, hi[d].y);
+    for (int d = 0; d < 8; ++d) f[d] = make_uint4(lo[d].x, lo[d].y, hi[d].x, hi[d].y);
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]));
+#pragma unroll
+    for (int d = 0; d < 8; ++d) f[d] = make_uint4(lo[d].x, lo[d].y, 0u, 0u);
+  }
 }
-
-__device__ __forceinline__ uint4 frag_g(const bf16_t* g, size_t ld, int row, int k0, int lane) {
-  return *reinterpret_cast<const uint4*>(g + (size_t)row * ld + k0 + 8 * (lane >> 4));
+// 4 consecutive head dims of one row -> 8-byte store; INV: conjugate RoPE (pairs p0, p0+1 of the row's tables)
+template <bool INV>
+__device__ __forceinline__ void store4(bf16_t* dst, const float (&x)[4], const float* c2, const float* s2) {
+  float y[4] = {x[0], x[1], x[2], x[3]};
+  if (INV) {
+    const float2 c = *reinterpret_cast<const float2*>(c2), s = *reinterpret_cast<const float2*>(s2);
+    y[0] = x[0] * c.x + x[1] * s.x; y[1] = x[1] * c.x - x[0] * s.x;
+    y[2] = x[2] * c.y + x[3] * s.y; y[3] = x[3] * c.y - x[2] * s.y;
+  }
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pack2(y[0], y[1]), pack2(y[2], y[3]));
+}
+// block-wide sum, blockDim.x == 512; `red` is 8 floats of LDS
+__device__ __forceinline__ float block_sum_512(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 
 // ------------------------------------------------------------------------------- forward
-// TR: take the V fragments with transposing LDS reads from the row-major tile (no transposed staging)
-template <bool TR>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+template <bool ROPE>
+__global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                        float* __restrict__ lse_a, float* __restrict__ lse_t,
                                                        const float* __restrict__ gate1,
                                                        const float* __restrict__ gate2,
-                                                       const int32_t* __restrict__ vstart, int n_seq, int S, int H,
-                                                       int A, int F) {
+                                                       const int32_t* __restrict__ vstart,
+                                                       const float* __restrict__ cs, const float* __restrict__ sn,
+                                                       int n_seq, int S, int H, int A, int F) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]
-  bf16_t* sVT = sK + KT * LDR;                            // [DH][LDT]  (TR: [KT][LDR] row-major V)
-  bf16_t* sP = sVT + (TR ? KT * LDR : DH * LDT);          // [4][16][LDP]
+  bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);      // [BQ][LDR]  K rows (rotated)
+  bf16_t* sV = sK + BQ * LDR;                             // [BQ][LDR]  V rows
+  bf16_t* sKa = sV + BQ * LDR;                            // [16][LDR]  adapter K rows (zero beyond A)
+  bf16_t* sVa = sKa + 16 * LDR;                           // [16][LDR]  adapter V rows
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
   const size_t ld = (size_t)3 * D;
   const bf16_t* seq = qkv + (size_t)n * S * ld + h * DH;
-  const int i0 = qb * QB + w * 16;                        // first query row of this wave
-  const int col = lane & 15, rq = (lane >> 4) * 4;        // C/D layout: rows rq..rq+3, column col
+  const int i0 = qb * BQ + w * 16;                        // first query of this wave
+  const int iq = i0 + li;                                 // this lane's query (score-block column)
+  const int iqc = iq < S ? iq : S - 1;
   const float sc = rsqrtf((float)DH);
 
   uint4 qf[4];
-  {
-    int r = i0 + (lane & 15);
-    r = r < S ? r : S - 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_g(seq, ld, r, 32 * ks, lane);
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = frag_g(seq, ld, iqc, 32 * ks, lane);
+    if (ROPE) qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
   }
+  const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
+  stage_tile<false, 16>(sKa, arow + D, ld, 0, A, nullptr, nullptr);
+  stage_tile<false, 16>(sVa, arow + 2 * D, ld, 0, A, nullptr, nullptr);
+
   f32x4 oacc[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m[4], ls[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { m[r] = NEG_BIG; ls[r] = 0.f; }
+  float m = NEG_BIG, ls = 0.f;                            // running max / this lane's part of the row sum
   const int vs = vstart[n];
   const float g2 = gate2[h];
-  bf16_t* myP = sP + w * 16 * LDP;
+  const bool biased_row = vs >= 0 && iq >= vs + F;
 
   for (int kt = 0; kt <= qb; ++kt) {
     __syncthreads();
-    stage_rows(sK, seq + D, ld, kt * KT, S, KT);
-    if (TR) stage_rows(sVT, seq + 2 * D, ld, kt * KT, S, KT);
-    else stage_rows_t(sVT, LDT, seq + 2 * D, ld, kt * KT, S, KT);
+    stage_tile<ROPE, BQ>(sK, seq + D, ld, kt * BQ, S, cs, sn);
+    stage_tile<false, BQ>(sV, seq + 2 * D, ld, kt * BQ, S, nullptr, nullptr);
     __syncthreads();
-    f32x4 s[4];
+    const int jlast = min(i0 + 15, S - 1) - kt * BQ;      // last tile-local key any row of this wave sees
+    const int ng = jlast < 0 ? 0 : min(4, (jlast >> 5) + 1);
+    for (int gq = 0; gq < ng; ++gq) {                     // 32 keys = two 16-key score blocks = one P·V k-step
+      f32x4 st[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      s[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 2; ++c) {
+        st[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[ct] = mma(qf[ks], frag(sK, LDR, 16 * ct, 32 * ks, lane), s[ct]);
-    }
-    float alpha[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = i0 + rq + r;
-      float mx = NEG_BIG;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const int j = kt * KT + 16 * ct + col;
-        float v = s[ct][r] * sc;
-        if (vs >= 0 && i >= vs + F && j >= vs && j < vs + F) v += g2;
-        v = (j <= i && j < S) ? v : NEG_BIG;
-        s[ct][r] = v;
-        mx = fmaxf(mx, v);
+        for (int ks = 0; ks < 4; ++ks) st[c] = mma(frag(sK, 32 * gq + 16 * c, 32 * ks, lane), qf[ks], st[c]);
       }
-      mx = group16_max(mx);
-      const float mn = fmaxf(m[r], mx);
-      alpha[r] = __expf(m[r] - mn);
-      m[r] = mn;
-      float rs = 0.f;
+      float v[2][4], mx = NEG_BIG;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const float p = (s[ct][r] > 0.5f * NEG_BIG) ? __expf(s[ct][r] - mn) : 0.f;
-        rs += p;
-        myP[(rq + r) * LDP + 16 * ct + col] = __float2bfloat16(p);
-      }
-      ls[r] = ls[r] * alpha[r] + rs;              // per-lane partial row sum (reduced at the end)
-    }
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int d = 0; d < 8; ++d)
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt * BQ + 32 * gq + 16 * c + 4 * g + r;
+          float x = st[c][r] * sc;
+          if (biased_row && j >= vs && j < vs + F) x += g2;
+          x = (j <= iq && j < S) ? x : NEG_BIG;
+          v[c][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      mx = across_g_max(mx);
+      const float mn = fmaxf(m, mx);
+      const float alpha = __expf(m - mn);
+      m = mn;
+      float p[2][4], rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha[r];
-    __syncthreads();                               // P tile visible (own wave), nobody still reads it
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      const uint4 pf = frag(myP, LDP, 0, 32 * k2, lane);
-      if (TR) {
-        uint4 vf8[8];
-        frags_tr8(sVT, 32 * k2, lane, vf8);
+        for (int r = 0; r < 4; ++r) {
+          p[c][r] = (v[c][r] > 0.5f * NEG_BIG) ? __expf(v[c][r] - mn) : 0.f;
+          rs += p[c][r];
+        }
+      ls = ls * alpha + rs;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, vf8[d], oacc[d]);
-      } else {
+      for (int d = 0; d < 8; ++d)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, frag(sVT, LDT, 16 * d, 32 * k2, lane), oacc[d]);
-      }
+        for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
+      const uint4 pf = pack_blocks(p[0], p[1]);
+      uint4 vf[8];
+      frags_tr_perm<true>(sV, 32 * gq, lane, vf);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) oacc[d] = mma(vf[d], pf, oacc[d]);
     }
   }
-  float lt[4];
+  const float l = across_g_sum(ls);
+  const float inv = 1.f / l;
+  const float lt = m + __logf(l);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float l = group16_sum(ls[r]);
-    const float inv = 1.f / l;
-    lt[r] = m[r] + __logf(l);
+  for (int d = 0; d < 8; ++d)
 #pragma unroll
-    for (int d = 0; d < 8; ++d) oacc[d][r] *= inv;
-  }
+    for (int r = 0; r < 4; ++r) oacc[d][r] *= inv;
 
-  // ---- adapter prefix tile (keys padded to 16 for S, to 32 for the P·V k-step)
-  const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
-  __syncthreads();
-  stage_rows(sK, arow + D, ld, 0, A, 16);
-  if (TR) stage_rows(sVT, arow + 2 * D, ld, 0, A, 32);
-  else stage_rows_t(sVT, LDT, arow + 2 * D, ld, 0, A, 32);
-  __syncthreads();
+  // ---- adapter prefix block: rows a = 4g+r of the score block, own softmax, scaled by tanh(gate1)
   f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) sa = mma(qf[ks], frag(sK, LDR, 0, 32 * ks, lane), sa);
+  for (int ks = 0; ks < 4; ++ks) sa = mma(frag(sKa, 0, 32 * ks, lane), qf[ks], sa);
   const float g1 = tanhf(gate1[h]);
-  float la[4];
+  float xa[4], mxa = NEG_BIG;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float v = (col < A) ? sa[r] * sc : NEG_BIG;
-    const float mx = group16_max(v);
-    const float e = (col < A) ? __expf(v - mx) : 0.f;
-    const float sum = group16_sum(e);
-    la[r] = mx + __logf(sum);
-    myP[(rq + r) * LDP + col] = __float2bfloat16(g1 * e / sum);
-    myP[(rq + r) * LDP + 16 + col] = __float2bfloat16(0.f);
+    xa[r] = (4 * g + r < A) ? sa[r] * sc : NEG_BIG;
+    mxa = fmaxf(mxa, xa[r]);
   }
-  __syncthreads();
+  mxa = across_g_max(mxa);
+  float ea[4], suma = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ea[r] = (4 * g + r < A) ? __expf(xa[r] - mxa) : 0.f;
+    suma += ea[r];
+  }
+  suma = across_g_sum(suma);
+  const float la = mxa + __logf(suma);
   {
-    const uint4 pf = frag(myP, LDP, 0, 0, lane);
-    if (TR) {
-      uint4 vf8[8];
-      frags_tr8(sVT, 0, lane, vf8);
+    const float sca = g1 / suma;
+    const float pa[4] = {ea[0] * sca, ea[1] * sca, ea[2] * sca, ea[3] * sca};
+    const uint4 pf = make_uint4(pack2(pa[0], pa[1]), pack2(pa[2], pa[3]), 0u, 0u);
+    uint4 vf[8];
+    frags_tr_perm<false>(sVa, 0, lane, vf);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, vf8[d], oacc[d]);
-    } else {
-#pragma unroll
-      for (int d = 0; d < 8; ++d) oacc[d] = mma(pf, frag(sVT, LDT, 16 * d, 0, lane), oacc[d]);
-    }
+    for (int d = 0; d < 8; ++d) oacc[d] = mma(vf[d], pf, oacc[d]);
   }
+  if (iq < S) {
+    bf16_t* orow = o + ((size_t)n * S + iq) * D + h * DH + 4 * g;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = i0 + rq + r;
-    if (i < S) {
-      bf16_t* orow = o + ((size_t)n * S + i) * D + h * DH;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) orow[16 * d + col] = __float2bfloat16(oacc[d][r]);
-      if (col == 0) {
-        lse_a[((size_t)n * H + h) * S + i] = la[r];
-        lse_t[((size_t)n * H + h) * S + i] = lt[r];
-      }
+    for (int d = 0; d < 8; ++d) {
+      const float x[4] = {oacc[d][0], oacc[d][1], oacc[d][2], oacc[d][3]};
+      store4<false>(orow + 16 * d, x, nullptr, nullptr);
+    }
+    if (g == 0) {
+      lse_a[((size_t)n * H + h) * S + iq] = la;
+      lse_t[((size_t)n * H + h) * S + iq] = lt;
     }
   }
 }
 
 // ------------------------------------------------------------------------------- backward: dQ
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_k(
+template <bool ROPE>
+__global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
     const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
     const float* __restrict__ lse_a, const float* __restrict__ lse_t, const float* __restrict__ gate1,
-    const float* __restrict__ gate2, const int32_t* __restrict__ vstart, bf16_t* __restrict__ dqkv,
-    float* __restrict__ delta_a, float* __restrict__ delta_t, float* __restrict__ gate_part, int n_seq, int S, int H,
-    int A, int F) {
+    const float* __restrict__ gate2, const int32_t* __restrict__ vstart, const float* __restrict__ cs,
+    const float* __restrict__ sn, bf16_t* __restrict__ dqkv, float* __restrict__ delta_a,
+    float* __restrict__ delta_t, float* __restrict__ gate_part, int n_seq, int S, int H, int A, int F) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]   K rows (also read column-wise for dS·K)
-  bf16_t* sV = sK + KT * LDR;                             // [KT][LDR]   V rows
-  bf16_t* sP = sV + KT * LDR;                             // [4][16][LDP] dS tile per wave
-  __shared__ float red[8];
+  bf16_t* sK = reinterpret_cast<bf16_t*>(smem_raw);      // [BQ][LDR] K rows (rotated): row reads for Sᵀ, column reads for Kᵀ·dS
+  bf16_t* sV = sK + BQ * LDR;                             // [BQ][LDR] V rows
+  bf16_t* sKa = sV + BQ * LDR;                            // [16][LDR]
+  bf16_t* sVa = sKa + 16 * LDR;                           // [16][LDR]
+  __shared__ float red[16];
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
   const size_t ld = (size_t)3 * D;
   const bf16_t* seq = qkv + (size_t)n * S * ld + h * DH;
-  const int i0 = qb * QB + w * 16;
-  const int col = lane & 15, rq = (lane >> 4) * 4;
+  const int i0 = qb * BQ + w * 16;
+  const int iq = i0 + li;
+  const int iqc = iq < S ? iq : S - 1;
+  const bool live = iq < S;
   const float sc = rsqrtf((float)DH);
   const size_t sbase = ((size_t)n * H + h) * S;
 
   uint4 qf[4], dof[4];
-  {
-    int r = i0 + (lane & 15);
-    r = r < S ? r : S - 1;
+  float dtot = 0.f;                                       // dO·O over the row: this lane's 32 dims, then across g
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qf[ks] = frag_g(seq, ld, r, 32 * ks, lane);
-      dof[ks] = frag_g(d_o + (size_t)n * S * D + h * DH, (size_t)D, r, 32 * ks, lane);
-    }
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = frag_g(seq, ld, iqc, 32 * ks, lane);
+    if (ROPE) qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
+    dof[ks] = frag_g(d_o + (size_t)n * S * D + h * DH, (size_t)D, iqc, 32 * ks, lane);
+    const uint4 of = frag_g(o + (size_t)n * S * D + h * DH, (size_t)D, iqc, 32 * ks, lane);
+    const unsigned tw[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w}, uw[4] = {of.x, of.y, of.z, of.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      dtot += __uint_as_float(tw[k] << 16) * __uint_as_float(uw[k] << 16) +
+              __uint_as_float(tw[k] & 0xFFFF0000u) * __uint_as_float(uw[k] & 0xFFFF0000u);
   }
-  // row statistics in C/D layout: rows i0+rq+r
-  float lsa[4], lst[4], dtot[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    int i = i0 + rq + r;
-    i = i < S ? i : S - 1;
-    lsa[r] = lse_a[sbase + i];
-    lst[r] = lse_t[sbase + i];
-    // dO·O over the row: each lane of the 16-lane group takes 8 of the 128 dims
-    const bf16_t* dor = d_o + ((size_t)n * S + i) * D + h * DH + col * 8;
-    const bf16_t* orr = o + ((size_t)n * S + i) * D + h * DH + col * 8;
-    float a[8], b[8];
-    {
-      const uint4 t = *reinterpret_cast<const uint4*>(dor), u = *reinterpret_cast<const uint4*>(orr);
-      const unsigned tw[4] = {t.x, t.y, t.z, t.w}, uw[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a[2 * k] = __uint_as_float(tw[k] << 16); a[2 * k + 1] = __uint_as_float(tw[k] & 0xFFFF0000u);
-        b[2 * k] = __uint_as_float(uw[k] << 16); b[2 * k + 1] = __uint_as_float(uw[k] & 0xFFFF0000u);
-      }
-    }
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc += a[k] * b[k];
-    dtot[r] = group16_sum(acc);
-  }
+  dtot = across_g_sum(dtot);
+  const float lsa = lse_a[sbase + iqc], lst = lse_t[sbase + iqc];
   const float g1 = tanhf(gate1[h]);
   const float g2 = gate2[h];
   const int vs = vstart[n];
-  bf16_t* myP = sP + w * 16 * LDP;
+  const bool biased_row = vs >= 0 && iq >= vs + F;
   f32x4 dq[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- adapter tile: dS_a, delta_a, d tanh-gate partial
+  // ---- adapter block: dS_a, delta_a, d tanh-gate partial
   const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
-  stage_rows(sK, arow + D, ld, 0, A, 32);                 // rows >= A are zero (32 = one MFMA k-step)
-  stage_rows(sV, arow + 2 * D, ld, 0, A, 16);
+  stage_tile<false, 16>(sKa, arow + D, ld, 0, A, nullptr, nullptr);
+  stage_tile<false, 16>(sVa, arow + 2 * D, ld, 0, A, nullptr, nullptr);
   __syncthreads();
-  float da[4], dg1 = 0.f;
+  float da, dg1 = 0.f, dg2 = 0.f;
   {
     f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dpa = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      sa = mma(qf[ks], frag(sK, LDR, 0, 32 * ks, lane), sa);
-      dpa = mma(dof[ks], frag(sV, LDR, 0, 32 * ks, lane), dpa);
+      sa = mma(frag(sKa, 0, 32 * ks, lane), qf[ks], sa);
+      dpa = mma(frag(sVa, 0, 32 * ks, lane), dof[ks], dpa);
     }
+    float pa[4], dov[4], part = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = (col < A) ? __expf(sa[r] * sc - lsa[r]) : 0.f;
-      const float dov = (col < A) ? dpa[r] : 0.f;
-      const bool live = i0 + rq + r < S;
-      if (live) dg1 += dov * p;
-      da[r] = group16_sum(p * g1 * dov);
-      const float ds = p * (g1 * dov - da[r]);
-      myP[(rq + r) * LDP + col] = __float2bfloat16(ds);
-      myP[(rq + r) * LDP + 16 + col] = __float2bfloat16(0.f);
+      const bool ok = 4 * g + r < A;
+      pa[r] = ok ? __expf(sa[r] * sc - lsa) : 0.f;
+      dov[r] = ok ? dpa[r] : 0.f;
+      if (live) dg1 += dov[r] * pa[r];
+      part += pa[r] * g1 * dov[r];
     }
-  }
-  __syncthreads();
-  {
-    const uint4 pf = frag(myP, LDP, 0, 0, lane);
+    da = across_g_sum(part);
+    const float ds[4] = {pa[0] * (g1 * dov[0] - da), pa[1] * (g1 * dov[1] - da), pa[2] * (g1 * dov[2] - da),
+                         pa[3] * (g1 * dov[3] - da)};
+    const uint4 sf = make_uint4(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), 0u, 0u);
     uint4 kf8[8];
-    frags_tr8(sK, 0, lane, kf8);
+    frags_tr_perm<false>(sKa, 0, lane, kf8);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) dq[d] = mma(pf, kf8[d], dq[d]);
+    for (int d = 0; d < 8; ++d) dq[d] = mma(kf8[d], sf, dq[d]);
   }
-  float dt[4], dg2 = 0.f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) dt[r] = dtot[r] - da[r];
+  const float dt = dtot - da;
 
   for (int kt = 0; kt <= qb; ++kt) {
     __syncthreads();
-    stage_rows(sK, seq + D, ld, kt * KT, S, KT);
-    stage_rows(sV, seq + 2 * D, ld, kt * KT, S, KT);
+    stage_tile<ROPE, BQ>(sK, seq + D, ld, kt * BQ, S, cs, sn);
+    stage_tile<false, BQ>(sV, seq + 2 * D, ld, kt * BQ, S, nullptr, nullptr);
     __syncthreads();
+    const int jlast = min(i0 + 15, S - 1) - kt * BQ;
+    const int ng = jlast < 0 ? 0 : min(4, (jlast >> 5) + 1);
+    for (int gq = 0; gq < ng; ++gq) {
+      f32x4 st[2], dpt[2];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 2; ++c) {
+        st[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dpt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = mma(qf[ks], frag(sK, LDR, 16 * ct, 32 * ks, lane), s);
-        dp = mma(dof[ks], frag(sV, LDR, 16 * ct, 32 * ks, lane), dp);
+        for (int ks = 0; ks < 4; ++ks) {
+          st[c] = mma(frag(sK, 32 * gq + 16 * c, 32 * ks, lane), qf[ks], st[c]);
+          dpt[c] = mma(frag(sV, 32 * gq + 16 * c, 32 * ks, lane), dof[ks], dpt[c]);
+        }
       }
+      float ds[2][4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = i0 + rq + r;
-        const int j = kt * KT + 16 * ct + col;
-        float v = s[r] * sc;
-        const bool inwin = vs >= 0 && i >= vs + F && j >= vs && j < vs + F;
-        if (inwin) v += g2;
-        const float p = (j <= i && j < S && i < S) ? __expf(v - lst[r]) : 0.f;
-        const float ds = p * (dp[r] - dt[r]);
-        if (inwin) dg2 += ds;
-        myP[(rq + r) * LDP + 16 * ct + col] = __float2bfloat16(ds);
-      }
-    }
-    __syncthreads();
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      const uint4 pf = frag(myP, LDP, 0, 32 * k2, lane);
+        for (int r = 0; r < 4; ++r) {
+          const int j = kt * BQ + 32 * gq + 16 * c + 4 * g + r;
+          float x = st[c][r] * sc;
+          const bool inwin = biased_row && j >= vs && j < vs + F;
+          if (inwin) x += g2;
+          const float p = (j <= iq && j < S && live) ? __expf(x - lst) : 0.f;
+          ds[c][r] = p * (dpt[c][r] - dt);
+          if (inwin) dg2 += ds[c][r];
+        }
+      const uint4 sf = pack_blocks(ds[0], ds[1]);
       uint4 kf8[8];
-      frags_tr8(sK, 32 * k2, lane, kf8);
+      frags_tr_perm<true>(sK, 32 * gq, lane, kf8);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) dq[d] = mma(pf, kf8[d], dq[d]);
+      for (int d = 0; d < 8; ++d) dq[d] = mma(kf8[d], sf, dq[d]);
     }
   }
+  if (live) {
+    bf16_t* row = dqkv + ((size_t)n * S + iq) * ld + h * DH + 4 * g;
+    const float* cr = ROPE ? cs + (size_t)iq * HP + 2 * g : nullptr;
+    const float* sr = ROPE ? sn + (size_t)iq * HP + 2 * g : nullptr;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = i0 + rq + r;
-    if (i < S) {
-      bf16_t* row = dqkv + ((size_t)n * S + i) * ld + h * DH;
-#pragma unroll
-      for (int d = 0; d < 8; ++d) row[16 * d + col] = __float2bfloat16(dq[d][r] * sc);
-      if (col == 0) {
-        delta_a[sbase + i] = da[r];
-        delta_t[sbase + i] = dt[r];
-      }
+    for (int d = 0; d < 8; ++d) {
+      const float x[4] = {dq[d][0] * sc, dq[d][1] * sc, dq[d][2] * sc, dq[d][3] * sc};
+      store4<ROPE>(row + 16 * d, x, cr + 8 * d, sr + 8 * d);
+    }
+    if (g == 0) {
+      delta_a[sbase + iq] = da;
+      delta_t[sbase + iq] = dt;
     }
   }
-  const float b1 = block_sum_256(dg1, red);
-  const float b2 = block_sum_256(dg2, red + 4);
+  const float b1 = block_sum_512(dg1, red);
+  const float b2 = block_sum_512(dg2, red + 8);
   if (threadIdx.x == 0) {
     const size_t pidx = (((size_t)n * H + h) * gridDim.x + qb) * 2;
     gate_part[pidx] = b1;
@@ -422,143 +446,147 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_k(
 }
 
 // ------------------------------------------------------------------------------- backward: dK, dV
-// blockIdx.x < nkb: 64 text keys (one 16-key tile per wave); blockIdx.x == nkb: the adapter keys
-// (16-key tile, every wave takes the query tiles t ≡ w mod 4 and the partial sums meet in LDS).
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_k(
+// blockIdx.x < nkb: 128 text keys (16 per wave); blockIdx.x == nkb: the adapter keys (one 16-key block;
+// waves 0-3 take the 32-query groups g ≡ w of every query tile and their partial sums meet in LDS).
+template <bool ROPE>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
     const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv, const float* __restrict__ lse_a,
     const float* __restrict__ lse_t, const float* __restrict__ delta_a, const float* __restrict__ delta_t,
     const float* __restrict__ gate1, const float* __restrict__ gate2, const int32_t* __restrict__ vstart,
-    bf16_t* __restrict__ dqkv, float* __restrict__ dka_part, float* __restrict__ dva_part, int n_seq, int S, int H,
-    int A, int F, int nkb) {
+    const float* __restrict__ cs, const float* __restrict__ sn, bf16_t* __restrict__ dqkv,
+    float* __restrict__ dka_part, float* __restrict__ dva_part, int n_seq, int S, int H, int A, int F, int nkb) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);      // [KT][LDR]  Q rows  (row reads for S^T, column reads for dK)
-  bf16_t* sdO = sQ + KT * LDR;                            // [KT][LDR]  dO rows (row reads for dP^T, column reads for dV)
-  bf16_t* sP = sdO + KT * LDR;                            // [4][2][16][LDP]  P^T and dS^T per wave
-  float* sL = reinterpret_cast<float*>(sP + 4 * 2 * 16 * LDP);   // [KT] lse, [KT] delta
-  float* sDl = sL + KT;
+  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);      // [BQ][LDR] Q rows (rotated): row reads for S, column reads for Qᵀ·dS
+  bf16_t* sdO = sQ + BQ * LDR;                            // [BQ][LDR] dO rows: row reads for dP, column reads for dOᵀ·P
+  float* sL = reinterpret_cast<float*>(sdO + BQ * LDR);   // [BQ] lse, [BQ] delta of the staged queries
+  float* sDl = sL + BQ;
   const int kb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const bool adapter = kb == nkb;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
   const size_t ld = (size_t)3 * D;
   const bf16_t* seq = qkv + (size_t)n * S * ld + h * DH;
   const bf16_t* dob = d_o + (size_t)n * S * D + h * DH;
-  const int col = lane & 15, rq = (lane >> 4) * 4;        // C/D layout: key rows rq..rq+3, query column col
   const float sc = rsqrtf((float)DH);
   const size_t sbase = ((size_t)n * H + h) * S;
-  bf16_t* myPT = sP + w * 2 * 16 * LDP;
-  bf16_t* myST = myPT + 16 * LDP;
   f32x4 dk[8], dv[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  const int nqt = (S + KT - 1) / KT;
+  const int nqt = (S + BQ - 1) / BQ;
   const float g1 = tanhf(gate1[h]);
 
-  // fragments of this wave's 16 keys (A operands of S^T and dP^T)
+  // this lane's key (score-block column) and its K / V operand fragments
+  const int j0 = adapter ? 0 : kb * BQ + w * 16;
+  const int jk = j0 + li;
+  const int limit = adapter ? A : S;
+  const bool kok = jk < limit;
   uint4 kf[4], vf[4];
-  const int j0 = adapter ? 0 : kb * QB + w * 16;
   {
     const bf16_t* kbase = adapter ? qkv + (size_t)n_seq * S * ld + h * DH : seq;
-    const int limit = adapter ? A : S;
-    int r = j0 + (lane & 15);
-    const bool ok = r < limit;
-    r = ok ? r : limit - 1;
+    const int jc = kok ? jk : limit - 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      kf[ks] = frag_g(kbase + D, ld, r, 32 * ks, lane);
-      vf[ks] = frag_g(kbase + 2 * D, ld, r, 32 * ks, lane);
-      if (!ok) { kf[ks] = make_uint4(0, 0, 0, 0); vf[ks] = make_uint4(0, 0, 0, 0); }
+      kf[ks] = frag_g(kbase + D, ld, jc, 32 * ks, lane);
+      if (ROPE && !adapter)
+        kf[ks] = rope8(kf[ks], cs + (size_t)jc * HP + 16 * ks + 4 * g, sn + (size_t)jc * HP + 16 * ks + 4 * g);
+      vf[ks] = frag_g(kbase + 2 * D, ld, jc, 32 * ks, lane);
+      if (!kok) { kf[ks] = make_uint4(0, 0, 0, 0); vf[ks] = make_uint4(0, 0, 0, 0); }
     }
   }
   const int vs = vstart[n];
   const float g2 = gate2[h];
+  const bool win_key = vs >= 0 && jk >= vs && jk < vs + F;
   const int t_first = adapter ? 0 : kb;
   for (int t = t_first; t < nqt; ++t) {
     __syncthreads();
-    stage_rows(sQ, seq, ld, t * KT, S, KT);
-    stage_rows(sdO, dob, (size_t)D, t * KT, S, KT);
-    if (threadIdx.x < KT) {
-      const int ii = min(t * KT + (int)threadIdx.x, S - 1);
+    stage_tile<ROPE, BQ>(sQ, seq, ld, t * BQ, S, cs, sn);
+    stage_tile<false, BQ>(sdO, dob, (size_t)D, t * BQ, S, nullptr, nullptr);
+    if (threadIdx.x < BQ) {
+      const int ii = min(t * BQ + (int)threadIdx.x, S - 1);
       sL[threadIdx.x] = adapter ? lse_a[sbase + ii] : lse_t[sbase + ii];
       sDl[threadIdx.x] = adapter ? delta_a[sbase + ii] : delta_t[sbase + ii];
     }
     __syncthreads();
-    const bool mine = !adapter || (t & 3) == w;      // adapter block: query tiles are dealt to the waves
-    if (mine) {
+    // 32-query groups of this tile that this wave works on
+    int gbeg, gend, gstep;
+    const int gmax = min(4, (min(S, (t + 1) * BQ) - t * BQ + 31) >> 5);          // groups holding real queries
+    if (adapter) { gbeg = w; gend = w < 4 ? gmax : 0; gstep = 4; }
+    else { gbeg = (t == kb) ? (w >> 1) : 0; gend = gmax; gstep = 1; }
+    for (int gq = gbeg; gq < gend; gq += gstep) {
+      f32x4 s[2], dp[2];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {                // 16-query column tiles of this 64-query tile
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 2; ++c) {
+        s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          s = mma(kf[ks], frag(sQ, LDR, 16 * ct, 32 * ks, lane), s);
-          dp = mma(vf[ks], frag(sdO, LDR, 16 * ct, 32 * ks, lane), dp);
+          s[c] = mma(frag(sQ, 32 * gq + 16 * c, 32 * ks, lane), kf[ks], s[c]);
+          dp[c] = mma(frag(sdO, 32 * gq + 16 * c, 32 * ks, lane), vf[ks], dp[c]);
         }
-        const int i = t * KT + 16 * ct + col;          // query of this lane's column
-        const float lse = sL[16 * ct + col], dl = sDl[16 * ct + col];
+      }
+      float p[2][4], ds[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(sL + 32 * gq + 16 * c + 4 * g);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sDl + 32 * gq + 16 * c + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = j0 + rq + r;                   // key row
-          float v = s[r] * sc;
-          float p, ds;
+          const int i = t * BQ + 32 * gq + 16 * c + 4 * g + r;      // query row of this register
+          float x = s[c][r] * sc;
           if (adapter) {
-            p = (j < A && i < S) ? __expf(v - lse) : 0.f;
-            ds = p * (g1 * dp[r] - dl);
-            p *= g1;
+            const float pp = (kok && i < S) ? __expf(x - lse4[r]) : 0.f;
+            ds[c][r] = pp * (g1 * dp[c][r] - dl4[r]);
+            p[c][r] = pp * g1;
           } else {
-            if (vs >= 0 && i >= vs + F && j >= vs && j < vs + F) v += g2;
-            p = (j <= i && i < S && j < S) ? __expf(v - lse) : 0.f;
-            ds = p * (dp[r] - dl);
+            if (win_key && i >= vs + F) x += g2;
+            const float pp = (jk <= i && i < S && kok) ? __expf(x - lse4[r]) : 0.f;
+            ds[c][r] = pp * (dp[c][r] - dl4[r]);
+            p[c][r] = pp;
           }
-          myPT[(rq + r) * LDP + 16 * ct + col] = __float2bfloat16(p);
-          myST[(rq + r) * LDP + 16 * ct + col] = __float2bfloat16(ds);
         }
       }
-    }
-    __syncthreads();
-    if (mine) {
+      const uint4 pf = pack_blocks(p[0], p[1]);
+      const uint4 sf = pack_blocks(ds[0], ds[1]);
+      uint4 t8[8];
+      frags_tr_perm<true>(sdO, 32 * gq, lane, t8);
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const uint4 pf = frag(myPT, LDP, 0, 32 * k2, lane);
-        const uint4 sf = frag(myST, LDP, 0, 32 * k2, lane);
-        uint4 t8[8];
-        frags_tr8(sdO, 32 * k2, lane, t8);
+      for (int d = 0; d < 8; ++d) dv[d] = mma(t8[d], pf, dv[d]);
+      frags_tr_perm<true>(sQ, 32 * gq, lane, t8);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) dv[d] = mma(pf, t8[d], dv[d]);
-        frags_tr8(sQ, 32 * k2, lane, t8);
-#pragma unroll
-        for (int d = 0; d < 8; ++d) dk[d] = mma(sf, t8[d], dk[d]);
-      }
+      for (int d = 0; d < 8; ++d) dk[d] = mma(t8[d], sf, dk[d]);
     }
   }
   if (!adapter) {
+    if (kok) {
+      bf16_t* row = dqkv + ((size_t)n * S + jk) * ld + h * DH + 4 * g;
+      const float* cr = ROPE ? cs + (size_t)jk * HP + 2 * g : nullptr;
+      const float* sr = ROPE ? sn + (size_t)jk * HP + 2 * g : nullptr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = j0 + rq + r;
-      if (j < S) {
-        bf16_t* row = dqkv + ((size_t)n * S + j) * ld + h * DH;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          row[D + 16 * d + col] = __float2bfloat16(dk[d][r] * sc);
-          row[2 * D + 16 * d + col] = __float2bfloat16(dv[d][r]);
-        }
+      for (int d = 0; d < 8; ++d) {
+        const float xk[4] = {dk[d][0] * sc, dk[d][1] * sc, dk[d][2] * sc, dk[d][3] * sc};
+        const float xv[4] = {dv[d][0], dv[d][1], dv[d][2], dv[d][3]};
+        store4<ROPE>(row + D + 16 * d, xk, cr + 8 * d, sr + 8 * d);
+        store4<false>(row + 2 * D + 16 * d, xv, nullptr, nullptr);
       }
     }
     return;
   }
-  // adapter block: sum the four waves' partial tiles through LDS ([wave][16][128] fp32 x 2 = 64 KiB,
-  // the Q/dO staging area is free now), then one fp32 partial per sequence for the batch reduction
+  // adapter block: sum the four working waves' partial blocks through LDS ([4][16][128] fp32 x 2 = 64 KiB, the
+  // Q/dO staging area is free now), then one fp32 partial per sequence for the batch reduction
   __syncthreads();
   float* rK = reinterpret_cast<float*>(smem_raw);
   float* rV = rK + 4 * 16 * DH;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
+  if (w < 4) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      rK[(w * 16 + rq + r) * DH + 16 * d + col] = dk[d][r] * sc;
-      rV[(w * 16 + rq + r) * DH + 16 * d + col] = dv[d][r];
+      *reinterpret_cast<f32x4*>(rK + (w * 16 + li) * DH + 16 * d + 4 * g) =
+          f32x4{dk[d][0] * sc, dk[d][1] * sc, dk[d][2] * sc, dk[d][3] * sc};
+      *reinterpret_cast<f32x4*>(rV + (w * 16 + li) * DH + 16 * d + 4 * g) = dv[d];
     }
+  }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < A * DH; idx += 256) {
+  for (int idx = threadIdx.x; idx < A * DH; idx += 512) {
     const int aa = idx / DH, d = idx % DH;
     float sk = 0.f, sv = 0.f;
 #pragma unroll
@@ -572,46 +600,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_k(
   }
 }
 
-constexpr size_t FWD_LDS = (size_t)(KT * LDR + DH * LDT + 4 * 16 * LDP) * 2;
-constexpr size_t FWD_LDS_TR = (size_t)(2 * KT * LDR + 4 * 16 * LDP) * 2;
-constexpr size_t DQ_LDS = (size_t)(2 * KT * LDR + 4 * 16 * LDP) * 2;
-constexpr size_t DKV_LDS_A = (size_t)(2 * KT * LDR + 4 * 2 * 16 * LDP) * 2 + 2 * KT * 4;
-constexpr size_t DKV_LDS_B = (size_t)2 * 4 * 16 * DH * 4;
-constexpr size_t DKV_LDS = DKV_LDS_A > DKV_LDS_B ? DKV_LDS_A : DKV_LDS_B;
+constexpr size_t FWD_LDS = (size_t)(2 * BQ + 32) * LDR * 2;
+constexpr size_t DKV_LDS = (size_t)2 * BQ * LDR * 2 + 2 * BQ * 4;
+static_assert(DKV_LDS >= (size_t)2 * 4 * 16 * DH * 4, "adapter reduction reuses the staging area");
+
+template <typename K>
+void allow_lds(K kernel, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 }  // namespace
 
-// launched from attn.hip's C entry points when dtype == bf16 (workspace layout shared with the vector build)
+// launched from attn.hip's C entry points when dtype == bf16 (workspace layout shared with the vector build).
+// cos_t/sin_t != NULL: q and k in `qkv` are the raw projections and RoPE is applied on the fly.
+int fvqa_attn_mfma_qblocks(int S) { return (S + BQ - 1) / BQ; }
+
 int fvqa_attn_fwd_mfma(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1, const float* gate2,
-                       const int32_t* vstart, int n_seq, int S, int H, int A, int F, hipStream_t st) {
-  const int nqb = (S + QB - 1) / QB;
-  static const bool tr = [] { const char* e = getenv("FVQA_ATTN_TR"); return !(e && e[0] == '0'); }();
-  if (tr) {
-    hipLaunchKernelGGL(attn_fwd_mfma_k<true>, dim3(nqb, H, n_seq), dim3(256), FWD_LDS_TR, st, (const bf16_t*)qkv,
-                       (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, A, F);
-  } else {
-    hipLaunchKernelGGL(attn_fwd_mfma_k<false>, dim3(nqb, H, n_seq), dim3(256), FWD_LDS, st, (const bf16_t*)qkv,
-                       (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, A, F);
+                       const int32_t* vstart, const float* cos_t, const float* sin_t, int n_seq, int S, int H, int A,
+                       int F, hipStream_t st) {
+  const int nqb = fvqa_attn_mfma_qblocks(S);
+  static bool attr = false;
+  if (!attr) {
+    allow_lds(attn_fwd_mfma_k<true>, FWD_LDS);
+    allow_lds(attn_fwd_mfma_k<false>, FWD_LDS);
+    attr = true;
   }
+  if (cos_t)
+    hipLaunchKernelGGL(attn_fwd_mfma_k<true>, dim3(nqb, H, n_seq), dim3(512), FWD_LDS, st, (const bf16_t*)qkv,
+                       (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, n_seq, S, H, A, F);
+  else
+    hipLaunchKernelGGL(attn_fwd_mfma_k<false>, dim3(nqb, H, n_seq), dim3(512), FWD_LDS, st, (const bf16_t*)qkv,
+                       (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, n_seq, S, H, A, F);
   return 0;
 }
 
 int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const float* lse_a, const float* lse_t,
-                       const float* gate1, const float* gate2, const int32_t* vstart, void* dqkv, float* delta_a,
-                       float* delta_t, float* gate_part, float* dka, float* dva, int n_seq, int S, int H, int A, int F,
-                       hipStream_t st) {
-  const int nqb = (S + QB - 1) / QB;
+                       const float* gate1, const float* gate2, const int32_t* vstart, const float* cos_t,
+                       const float* sin_t, void* dqkv, float* delta_a, float* delta_t, float* gate_part, float* dka,
+                       float* dva, int n_seq, int S, int H, int A, int F, hipStream_t st) {
+  const int nqb = fvqa_attn_mfma_qblocks(S);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DQ_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DKV_LDS);
+    allow_lds(attn_bwd_dq_mfma_k<true>, FWD_LDS);
+    allow_lds(attn_bwd_dq_mfma_k<false>, FWD_LDS);
+    allow_lds(attn_bwd_dkv_mfma_k<true>, DKV_LDS);
+    allow_lds(attn_bwd_dkv_mfma_k<false>, DKV_LDS);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_k, dim3(nqb, H, n_seq), dim3(256), DQ_LDS, st, (const bf16_t*)d_o,
-                     (const bf16_t*)qkv, (const bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, (bf16_t*)dqkv, delta_a,
-                     delta_t, gate_part, n_seq, S, H, A, F);
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_k, dim3(nqb + 1, H, n_seq), dim3(256), DKV_LDS, st, (const bf16_t*)d_o,
-                     (const bf16_t*)qkv, lse_a, lse_t, delta_a, delta_t, gate1, gate2, vstart, (bf16_t*)dqkv, dka, dva,
-                     n_seq, S, H, A, F, nqb);
+#define FVQA_BWD(R)                                                                                                   \
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_k<R>, dim3(nqb, H, n_seq), dim3(512), FWD_LDS, st, (const bf16_t*)d_o,           \
+                     (const bf16_t*)qkv, (const bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t,          \
+                     (bf16_t*)dqkv, delta_a, delta_t, gate_part, n_seq, S, H, A, F);                                  \
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_k<R>, dim3(nqb + 1, H, n_seq), dim3(512), DKV_LDS, st, (const bf16_t*)d_o,      \
+                     (const bf16_t*)qkv, lse_a, lse_t, delta_a, delta_t, gate1, gate2, vstart, cos_t, sin_t,          \
+                     (bf16_t*)dqkv, dka, dva, n_seq, S, H, A, F, nqb);
+  if (cos_t) { FVQA_BWD(true) } else { FVQA_BWD(false) }
+#undef FVQA_BWD
   return 0;
 }

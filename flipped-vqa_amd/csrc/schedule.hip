@@ -74,6 +74,7 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
   const int R = n_seq * S, Ra = R + A;
   const size_t es = fvqa_dtype_size(dt);
   char* xn_tail = at(p->xn, (size_t)R * D, es);
+  const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
   RUN(fvqa_rmsnorm_fwd(p->xs, p->an[0], p->xn, p->rstd1, R, D, p->eps, dt, stream));
   for (int i = 0; i < L; ++i) {
     const void* x = at(p->xs, (size_t)i * R * D, es);
@@ -87,9 +88,14 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     RUN(fvqa_cast_rows(p->adapter + (size_t)i * A * D, xn_tail, A, D, dt, stream));
     RUN(fvqa_gemm_nt(p->xn, p->wqkv[i], qkv, nullptr, nullptr, Ra, 3 * D, D, D, D, 3 * D, Ra, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
-    RUN(fvqa_rope_qk(qkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 0, dt, stream));
-    RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, n_seq, S, H, Dh, A, p->max_feats, dt,
-                      stream));
+    if (fused_rope) {                                  // bf16 MFMA build: q,k stay raw and are rotated inside
+      RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t, n_seq, S, H, Dh,
+                        A, p->max_feats, dt, stream));
+    } else {
+      RUN(fvqa_rope_qk(qkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 0, dt, stream));
+      RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, nullptr, nullptr, n_seq, S, H, Dh, A,
+                        p->max_feats, dt, stream));
+    }
     // WO: split-K partials summed by the fused residual + ffn-norm kernel
     int sp = fvqa_gemm_splits(R, D, D, dt);
     RUN(fvqa_gemm_nt(o, p->wo[i], nullptr, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_PARTIAL, 0,
@@ -126,6 +132,7 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
   const size_t es = fvqa_dtype_size(dt);
   void* cur = p->dcur;
   void* nxt = p->dnxt;
+  const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
   RUN(fvqa_rmsnorm_bwd(dxnf, at(p->xs, (size_t)L * R * D, es), p->norm_w, p->rstdN, nullptr, cur, R, D, dt, stream));
   for (int i = L - 1; i >= 0; --i) {
     const void* x = at(p->xs, (size_t)i * R * D, es);
@@ -145,9 +152,16 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
                              p->dh, nullptr, 0, R, D, dt, stream));
     RUN(fvqa_gemm_nt(p->dh, p->wo_t[i], p->d_o, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
-    RUN(fvqa_attn_bwd(p->d_o, qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->dqkv, p->dgate1[i],
-                      p->dgate2[i], p->attn_ws, p->attn_ws_bytes, n_seq, S, H, Dh, A, p->max_feats, dt, stream));
-    RUN(fvqa_rope_qk(p->dqkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 1, dt, stream));
+    if (fused_rope) {
+      RUN(fvqa_attn_bwd(p->d_o, qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t, p->dqkv,
+                        p->dgate1[i], p->dgate2[i], p->attn_ws, p->attn_ws_bytes, n_seq, S, H, Dh, A, p->max_feats, dt,
+                        stream));
+    } else {
+      RUN(fvqa_attn_bwd(p->d_o, qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, nullptr, nullptr, p->dqkv,
+                        p->dgate1[i], p->dgate2[i], p->attn_ws, p->attn_ws_bytes, n_seq, S, H, Dh, A, p->max_feats, dt,
+                        stream));
+      RUN(fvqa_rope_qk(p->dqkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 1, dt, stream));
+    }
     sp = fvqa_gemm_splits(Ra, D, 3 * D, dt);
     RUN(fvqa_gemm_nt(p->dqkv, p->wqkv_t[i], nullptr, nullptr, nullptr, Ra, D, 3 * D, 3 * D, 3 * D, D, Ra, dt, dt,
                      FVQA_EPI_PARTIAL, 0, p->gemm_ws, p->gemm_ws_bytes, stream));

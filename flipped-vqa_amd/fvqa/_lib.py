@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL, EPI_SWIGLU_BWD = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -32,9 +32,10 @@ SIGNATURES = {
     "fvqa_rope_qk": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_swiglu_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "fvqa_swiglu_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    "fvqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_attn_rope_fused": (_i, [_i]),
+    "fvqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_attn_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
-    "fvqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_visual_proj_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fvqa_visual_proj_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fvqa_embed_splice": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -294,8 +294,26 @@ def _attn_shapes(qkv, n_seq, S, H, Dh, A):
     return D
 
 
-def attn_fwd(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, Dh, A, F):
+def attn_rope_fused(dtype: torch.dtype) -> bool:
+    """True when attn_fwd / attn_bwd of this dtype rotate q,k themselves (rope=(cos, sin) argument)."""
+    return bool(_lib.load().fvqa_attn_rope_fused(dt_code(dtype)))
+
+
+def _rope_tables(rope, S, Dh, what):
+    if rope is None:
+        return None, None
+    cos_t, sin_t = rope
+    _dev(cos_t, sin_t)
+    _need(cos_t.dtype == sin_t.dtype == torch.float32 and cos_t.shape == sin_t.shape and
+          cos_t.shape[-1] == Dh // 2 and cos_t.shape[0] >= S and cos_t.is_contiguous() and sin_t.is_contiguous(),
+          f"{what}: rope tables")
+    return cos_t, sin_t
+
+
+def attn_fwd(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, Dh, A, F, rope=None):
+    """rope=(cos_t, sin_t): qkv holds the raw projections and RoPE is applied inside (attn_rope_fused)."""
     _dev(qkv, o, lse_a, lse_t, gate1, gate2, vstart)
+    cos_t, sin_t = _rope_tables(rope, S, Dh, "attn_fwd")
     D = _attn_shapes(qkv, n_seq, S, H, Dh, A)
     _need(o.dtype == qkv.dtype and tuple(o.shape) == (n_seq * S, D), "attn_fwd: o shape")
     for t in (lse_a, lse_t):
@@ -304,7 +322,8 @@ def attn_fwd(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, Dh, A, F):
         _need(t.dtype == torch.float32 and t.numel() == H, "attn_fwd: gate shape")
     _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "attn_fwd: vstart")
     rc = _lib.load().fvqa_attn_fwd(_ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1), _ptr(gate2),
-                                   _ptr(vstart), n_seq, S, H, Dh, A, F, dt_code(qkv.dtype), _stream())
+                                   _ptr(vstart), _ptr(cos_t), _ptr(sin_t), n_seq, S, H, Dh, A, F,
+                                   dt_code(qkv.dtype), _stream())
     _lib.check(rc, "fvqa_attn_fwd")
     return o
 
@@ -314,8 +333,9 @@ def attn_bwd_workspace(n_seq, S, H, Dh, A) -> int:
 
 
 def attn_bwd(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace,
-             n_seq, S, H, Dh, A, F):
+             n_seq, S, H, Dh, A, F, rope=None):
     _dev(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace)
+    cos_t, sin_t = _rope_tables(rope, S, Dh, "attn_bwd")
     D = _attn_shapes(qkv, n_seq, S, H, Dh, A)
     _need(dqkv.dtype == qkv.dtype and dqkv.shape == qkv.shape, "attn_bwd: dqkv shape")
     for t in (d_o, o):
@@ -328,8 +348,8 @@ def attn_bwd(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgat
     wbytes = workspace.numel() * workspace.element_size()
     _need(wbytes >= attn_bwd_workspace(n_seq, S, H, Dh, A), "attn_bwd: workspace too small")
     rc = _lib.load().fvqa_attn_bwd(_ptr(d_o), _ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1),
-                                   _ptr(gate2), _ptr(vstart), _ptr(dqkv), _ptr(dgate1), _ptr(dgate2),
-                                   _ptr(workspace), wbytes, n_seq, S, H, Dh, A, F, dt_code(qkv.dtype), _stream())
+                                   _ptr(gate2), _ptr(vstart), _ptr(cos_t), _ptr(sin_t), _ptr(dqkv), _ptr(dgate1),
+                                   _ptr(dgate2), _ptr(workspace), wbytes, n_seq, S, H, Dh, A, F, dt_code(qkv.dtype), _stream())
     _lib.check(rc, "fvqa_attn_bwd")
     return dqkv
 

@@ -297,9 +297,13 @@ class StepEngine:
             x = ar.xs[i]
             ops.cast_rows(adapter[i], ar.xn[R:Ra])
             ops.gemm_nt(ar.xn, pk.wqkv[i], ar.qkv[i])
-            ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
             g1, g2 = m.gate_views(i)
-            ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
+            if ops.attn_rope_fused(self.dtype):             # bf16 MFMA build: q,k stay raw, rotated inside
+                ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F,
+                             rope=(self.cos, self.sin))
+            else:
+                ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
+                ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
             ws, _ = ops.gemm_nt_partial(ar.o[i], pk.wo[i])
             ops.sumres_rmsnorm_fwd(ws, x, pk.fn[i], ar.h[i], ar.hn, ar.rstd2[i], self.eps, R)
             ops.gemm_nt(ar.hn, pk.w13[i], ar.ab[i])
@@ -368,9 +372,13 @@ class StepEngine:
             ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)
             g1, g2 = m.gate_views(i)
             dg1, dg2 = grads.gate_grad_views(i)
-            ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1, dg2,
-                         ar.attn_ws, n_seq, S, H, Dh, A, F)
-            ops.rope_qk(ar.dqkv, self.cos, self.sin, n_seq, S, H, Dh, inverse=True)
+            if ops.attn_rope_fused(self.dtype):
+                ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1,
+                             dg2, ar.attn_ws, n_seq, S, H, Dh, A, F, rope=(self.cos, self.sin))
+            else:
+                ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1,
+                             dg2, ar.attn_ws, n_seq, S, H, Dh, A, F)
+                ops.rope_qk(ar.dqkv, self.cos, self.sin, n_seq, S, H, Dh, inverse=True)
             ws, _ = ops.gemm_nt_partial(ar.dqkv, pk.wqkv_t[i])
             ops.sum_rmsnorm_bwd(ws, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, R, resid=ar.dh, tail=g_adapter[i])
             cur, nxt = nxt, cur

@@ -112,16 +112,24 @@ int fvqa_swiglu_bwd(const void* dz, const void* ab, void* dab, int rows, int hid
  * gate1, gate2: (H) fp32. vstart: (n_seq) int32, -1 ⇒ no gate2 bias for that sequence
  * (the QAV stream, llama/model.py:121-122). lse_a/lse_t: (n_seq, H, S) fp32 log-sum-exp of
  * the adapter softmax and of the causal softmax, saved for the backward. */
+/* cos_t/sin_t (both NULL or both given): when given, q and k in `qkv` are the RAW projections and the
+ * kernel rotates them on the fly with the tables of fvqa_rope_qk (identical values to the separate
+ * pass; llama/model.py:96); only builds for which fvqa_attn_rope_fused(dtype) == 1 accept them. */
+int fvqa_attn_rope_fused(int dtype);
 int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1,
-                  const float* gate2, const int32_t* vstart, int n_seq, int seq_len, int n_heads,
-                  int head_dim, int adapter_len, int max_feats, int dtype, void* stream);
+                  const float* gate2, const int32_t* vstart, const float* cos_t, const float* sin_t,
+                  int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
+                  int dtype, void* stream);
 /* workspace bytes fvqa_attn_bwd needs (fp32 partials for the batch-summed adapter k/v
  * gradients and the per-head gate sums) */
 size_t fvqa_attn_bwd_workspace(int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len);
-/* dqkv: (n_seq*S + A, 3*dim): dq,dk,dv for sequence rows (RoPE NOT yet inverted); adapter rows
- * get [0, dK_a, dV_a] summed over sequences. dgate1/dgate2 (H) fp32 are ACCUMULATED (+=). */
+/* dqkv: (n_seq*S + A, 3*dim): dq,dk,dv for sequence rows; adapter rows get [0, dK_a, dV_a] summed over
+ * sequences. With cos_t/sin_t == NULL, qkv holds rotated q,k and dq,dk come out NOT yet un-rotated
+ * (fvqa_rope_qk inverse follows); with the tables, qkv is raw and dq,dk are gradients of the raw
+ * projections. dgate1/dgate2 (H) fp32 are ACCUMULATED (+=). */
 int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, const float* lse_a,
                   const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
+                  const float* cos_t, const float* sin_t,
                   void* dqkv, float* dgate1, float* dgate2, void* workspace, size_t workspace_bytes,
                   int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
                   int dtype, void* stream);

@@ -35,6 +35,9 @@ CASES = {
     "small_all": ("small", dict(vaq=True, qav=True)),
     "7b_l2_all": ("7b_l2", dict(vaq=True, qav=True)),
     "7b_l2_vqa": ("7b_l2", dict(vaq=False, qav=False)),
+    # BASELINE configs[0] (C1): the full 32-layer 7B, B=2, S=128, all three losses (~30 GB of fp32
+    # weights in the reference: generated tensor by tensor; a few minutes on 8 cores)
+    "7b_full_all": ("7b", dict(batch_size=2, vaq=True, qav=True)),
 }
 
 
@@ -77,10 +80,11 @@ def build_reference(M, cfg):
     finally:
         for fn, f in saved.items():
             setattr(torch.nn.init, fn, f)
-    sd = synth.state_dict(cfg)
+    spec = {n: (shape, kind) for n, shape, kind in synth.state_spec(cfg)}
     with torch.no_grad():
-        for n, p in model.named_parameters():
-            p.data = sd[n].clone()
+        for n, p in model.named_parameters():      # one tensor at a time: the full 7B is 27 GB in fp32
+            shape, kind = spec[n]
+            p.data = synth.make_tensor(cfg, n, shape, kind)
     for n, p in model.named_parameters():          # llama_vqa.py:71-76
         p.requires_grad = synth.is_trainable(n)
     return model, args

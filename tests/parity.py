@@ -15,6 +15,9 @@ CASES = {
     "small_all": ("small", dict(vaq=True, qav=True)),
     "7b_l2_all": ("7b_l2", dict(vaq=True, qav=True)),
     "7b_l2_vqa": ("7b_l2", dict(vaq=False, qav=False)),
+    # BASELINE configs[0]: the full 32-layer 7B, B=2, S=128, three losses (GPU parity only: the fp64
+    # oracle of this size does not fit the CPU test budget)
+    "7b_full_all": ("7b", dict(batch_size=2, vaq=True, qav=True)),
 }
 
 

@@ -256,7 +256,7 @@ def _attn_case(dtype, N, S, H, A, F, vstart, seed=0):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,S,H,vstart", [(2, 32, 2, [5, -1]), (3, 128, 2, [19, 19, -1]), (1, 200, 1, [19]),
-                                          (2, 70, 3, [-1, 8])])
+                                          (2, 70, 3, [-1, 8]), (1, 650, 1, [19]), (2, 129, 1, [100, -1])])
 def test_attention_fwd_bwd(dtype, N, S, H, vstart):
     A, F = 10, 10
     qkv, g1, g2, vs, Dh, D = _attn_case(dtype, N, S, H, A, F, vstart, seed=S)
@@ -294,6 +294,79 @@ def test_attention_fwd_bwd(dtype, N, S, H, vstart):
     assert float(got[N * S:, :D].abs().max()) == 0.0
     assert rel(dg1d - 1.0, dg1) < max(t, 1e-4)
     assert rel(dg2d - 1.0, dg2) < max(t, 1e-4)
+
+
+@pytest.mark.parametrize("N,S,H,vstart", [(2, 128, 2, [19, -1]), (1, 300, 1, [19]), (2, 70, 3, [-1, 8])])
+def test_attention_fused_rope_bf16(N, S, H, vstart):
+    """bf16 MFMA build with RoPE applied inside (raw q,k in, gradients of the raw projections out) against
+    (a) the fp64 oracle fed RoPE'd operands, (b) the unfused sequence rope_qk -> attention -> inverse rope_qk."""
+    dtype = torch.bfloat16
+    if not ops.attn_rope_fused(dtype):
+        pytest.skip("vector attention build selected (FVQA_ATTN_VALU=1)")
+    A, F = 10, 10
+    qkv, g1, g2, vs, Dh, D = _attn_case(dtype, N, S, H, A, F, vstart, seed=S + 1)
+    d_o = rnd(N * S, D, dtype=dtype, seed=78)
+    cos, sin = ref_cpu.rope_tables(2 * S, Dh, torch.float32)
+    cd, sd = dev(cos), dev(sin)
+    qkv_d, g1d, g2d, vsd = dev(qkv), dev(g1), dev(g2), dev(vs)
+
+    def run(fused):
+        buf = qkv_d.clone()
+        o = torch.empty(N * S, D, dtype=dtype, device=DEV)
+        la = torch.empty(N * H * S, dtype=torch.float32, device=DEV)
+        lt = torch.empty_like(la)
+        dqkv = torch.full((N * S + A, 3 * D), float("nan"), dtype=dtype, device=DEV)
+        dg1, dg2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        ws = torch.empty(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
+        rope = (cd, sd) if fused else None
+        if not fused:
+            ops.rope_qk(buf, cd, sd, N, S, H, Dh)
+        ops.attn_fwd(buf, o, la, lt, g1d, g2d, vsd, N, S, H, Dh, A, F, rope=rope)
+        ops.attn_bwd(dev(d_o), buf, o, la, lt, g1d, g2d, vsd, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, rope=rope)
+        if not fused:
+            ops.rope_qk(dqkv, cd, sd, N, S, H, Dh, inverse=True)
+        return o.float().cpu(), dqkv.float().cpu(), dg1.cpu(), dg2.cpu(), la.cpu(), lt.cpu()
+
+    of, dqf, dg1f, dg2f, laf, ltf = run(True)
+    ou, dqu, dg1u, dg2u, lau, ltu = run(False)
+    # the rotated operands are bit-identical in both runs; only the gradient's un-rotation rounds differently
+    assert rel(of, ou) < 1e-5 and rel(laf, lau) < 1e-6 and rel(ltf, ltu) < 1e-6
+    assert not torch.isnan(dqf).any()
+    assert rel(dqf, dqu) < 6e-3
+    assert rel(dg1f, dg1u) < 1e-4 and rel(dg2f, dg2u) < 1e-4
+
+    # oracle on the rotated operands; gradients rotated back (conjugate) for the comparison
+    q = qkv[: N * S, :D].double().view(N, S, H, Dh)
+    k = qkv[: N * S, D:2 * D].double().view(N, S, H, Dh)
+    v = qkv[: N * S, 2 * D:].double().view(N, S, H, Dh)
+    ak = qkv[N * S:, D:2 * D].double().view(A, H, Dh)
+    av = qkv[N * S:, 2 * D:].double().view(A, H, Dh)
+    c64, s64 = cos[:S].double(), sin[:S].double()
+    qr = ref_cpu.rope_apply(q, c64, s64).to(dtype).double()
+    kr = ref_cpu.rope_apply(k, c64, s64).to(dtype).double()
+    o_ref, cache = ref_cpu.attn_fwd(qr, kr, v, ak, av, g1.double(), g2.double(), vstart, F)
+    assert rel(of, o_ref.reshape(N * S, D)) < 1e-2
+    dq, dk, dv, dak, dav, dg1, dg2 = ref_cpu.attn_bwd(d_o.double().view(N, S, H, Dh), qr, kr, v, ak, av, g1.double(),
+                                                      g2.double(), vstart, F, cache)
+    dq = ref_cpu.rope_apply(dq, c64, -s64)
+    dk = ref_cpu.rope_apply(dk, c64, -s64)
+    # the backward above consumed the kernel's own rounded o; compare with bf16 tolerances
+    assert rel(dqf[: N * S, :D], dq.reshape(N * S, D)) < 2e-2
+    assert rel(dqf[: N * S, D:2 * D], dk.reshape(N * S, D)) < 2e-2
+    assert rel(dqf[: N * S, 2 * D:], dv.reshape(N * S, D)) < 2e-2
+    assert rel(dqf[N * S:, D:2 * D], dak.reshape(A, D)) < 2e-2
+    assert rel(dqf[N * S:, 2 * D:], dav.reshape(A, D)) < 2e-2
+
+
+def test_attention_rope_tables_rejected_by_vector_build():
+    N, S, H, A, F = 1, 32, 1, 10, 10
+    qkv, g1, g2, vs, Dh, D = _attn_case(torch.float32, N, S, H, A, F, [5], seed=4)
+    cos, sin = ref_cpu.rope_tables(64, Dh, torch.float32)
+    o = torch.empty(N * S, D, device=DEV)
+    la = torch.empty(N * H * S, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(dev(qkv), o, la, torch.empty_like(la), dev(g1), dev(g2), dev(vs), N, S, H, Dh, A, F,
+                     rope=(dev(cos), dev(sin)))
 
 
 def test_attention_is_deterministic():

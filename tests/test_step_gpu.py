@@ -19,7 +19,8 @@ BF16_LOSS_RTOL = 2e-2   # bf16 storage (8-bit mantissa) through L layers
 BF16_GRAD_RTOL = 8e-2
 
 
-@pytest.mark.parametrize("case", ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "7b_l2_all", "7b_l2_vqa"])
+@pytest.mark.parametrize("case", ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "7b_l2_all", "7b_l2_vqa",
+                                  "7b_full_all"])
 def test_fp32_step_matches_reference_golden(case):
     pname, over = CASES[case]
     cfg = synth.preset(pname, **over)
@@ -30,6 +31,8 @@ def test_fp32_step_matches_reference_golden(case):
     print(case, {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
     # the fp32 build is in fact far inside the bar
     assert rep["loss_vqa"] < 1e-4
+    del model
+    torch.cuda.empty_cache()
 
 
 def _oracle(cfg, sd, batch, weights=(1.0, 1.0, 1.0)):

@@ -46,6 +46,19 @@ for name, M, N, K in SHAPES:
         tot[v] += t
         sp = lib.fvqa_gemm_splits(M, N, K, 1) if v in (0, 3) else (v - 16 if v >= 16 else 1)
         cells.append(f"{t:8.1f} {2.0 * M * N * K / t / 1e6:7.0f} {err:8.1e} s{sp}")
+    if os.environ.get("GB_TORCH") == "1":          # vendor library (hipBLASLt through torch) on the same operands
+        ts = []
+        bt = b.T
+        for r in range(ROUNDS + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.matmul(a, bt)
+            e1.record()
+            torch.cuda.synchronize()
+            if r:
+                ts.append(e0.elapsed_time(e1) * 1e3)
+        t = sorted(ts)[len(ts) // 2]
+        cells.append(f"| torch.matmul {t:8.1f} us {2.0 * M * N * K / t / 1e6:7.0f} TF")
     print(f"{name:10s} {M:5d} {N:6d} {K:6d} " + "  ".join(cells), flush=True)
 print("sum per layer-equivalent (us):", {v: round(t, 1) for v, t in tot.items()})
 

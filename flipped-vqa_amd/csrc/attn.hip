@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_k(const float* __restrict
 }
 
 struct BwdWs {
-  size_t delta_a, delta_t, gate_part, dka, dva, total;
+  size_t arrive, delta_a, delta_t, gate_part, dka, dva, total;
 };
 inline BwdWs bwd_ws(int n_seq, int S, int H, int A) {
   BwdWs w;
@@ -453,6 +453,8 @@ inline BwdWs bwd_ws(int n_seq, int S, int H, int A) {
   const size_t nqb = (S + TILE - 1) / TILE;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += (n * 4 + 255) & ~(size_t)255; return o; };
+  w.arrive = take(256);                 // per-head arrival counters of the fused bf16 backward: zero on first use,
+                                        // left zero on return (include/fvqa.h)
   w.delta_a = take(nhs);
   w.delta_t = take(nhs);
   w.gate_part = take((size_t)n_seq * H * nqb * 2);
@@ -478,8 +480,9 @@ int fvqa_attn_fwd_mfma(const void* qkv, void* o, float* lse_a, float* lse_t, con
                        int F, hipStream_t st);
 int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const float* lse_a, const float* lse_t,
                        const float* gate1, const float* gate2, const int32_t* vstart, const float* cos_t,
-                       const float* sin_t, void* dqkv, float* delta_a, float* delta_t, float* gate_part, float* dka,
-                       float* dva, int n_seq, int S, int H, int A, int F, hipStream_t st);
+                       const float* sin_t, void* dqkv, float* dgate1, float* dgate2, float* delta_a, float* delta_t,
+                       float* gate_part, float* dka, float* dva, int* arrive, int n_seq, int S, int H, int A, int F,
+                       hipStream_t st);
 static bool use_mfma_attention() {
   static const bool v = [] { const char* e = getenv("FVQA_ATTN_VALU"); return !(e && e[0] == '1'); }();
   return v;
@@ -549,10 +552,12 @@ extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, co
   const size_t lds_q = (size_t)(2 * TILE + 2 * adapter_len) * DH * sizeof(float);
   const size_t lds_kv = (size_t)(2 * TILE * DH + 2 * TILE) * sizeof(float);
   if (dtype == FVQA_BF16 && use_mfma_attention()) {
-    fvqa_attn_bwd_mfma(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, dqkv, delta_a, delta_t,
-                       gate_part, dka, dva, n_seq, seq_len, n_heads, adapter_len, max_feats, st);
-    hipLaunchKernelGGL(attn_bwd_reduce_k<bf16_t>, dim3(64), block, 0, st, dka, dva, gate_part, gate1, (bf16_t*)dqkv,
-                       dgate1, dgate2, n_seq, seq_len, n_heads, adapter_len, fvqa_attn_mfma_qblocks(seq_len));
+    const int reduced = fvqa_attn_bwd_mfma(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, dqkv, dgate1,
+                                           dgate2, delta_a, delta_t, gate_part, dka, dva, (int*)(wb + ws.arrive), n_seq,
+                                           seq_len, n_heads, adapter_len, max_feats, st);
+    if (!reduced)
+      hipLaunchKernelGGL(attn_bwd_reduce_k<bf16_t>, dim3(64), block, 0, st, dka, dva, gate_part, gate1, (bf16_t*)dqkv,
+                         dgate1, dgate2, n_seq, seq_len, n_heads, adapter_len, fvqa_attn_mfma_qblocks(seq_len));
     FVQA_CHECK_LAUNCH();
     return FVQA_OK;
   }

@@ -73,28 +73,33 @@ __device__ __forceinline__ uint4 rope8(const uint4& v, const float* c4, const fl
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// stage NR rows x 128 of a row-major global matrix (row stride ld elements) into sR[NR][LDR]; rows >= row_limit
-// are zero-filled; ROPE rotates the row with the tables of position (row index)
-template <bool ROPE, int NR>
-__device__ __forceinline__ void stage_tile(bf16_t* sR, const bf16_t* g, size_t ld, int row0, int row_limit,
-                                           const float* cs, const float* sn) {
-  constexpr int PER = (NR * 16 + 511) / 512;
-  uint4 v[PER];
+// Staging of NR rows x 128 of a row-major global matrix (row stride ld elements) into sR[NR][LDR] in two
+// halves, so that a kernel can put ALL its global loads in flight before the first wait: tile_load issues the
+// 16-byte loads into registers (rows >= row_limit are zero), tile_commit rotates (ROPE: tables of position
+// = row index) and writes LDS.
+template <int NR> struct TileRegs { uint4 v[(NR * 16 + 511) / 512]; };
+template <int NR>
+__device__ __forceinline__ void tile_load(TileRegs<NR>& t, const bf16_t* g, size_t ld, int row0, int row_limit) {
 #pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int idx = threadIdx.x + t * 512;
+  for (int u = 0; u < (NR * 16 + 511) / 512; ++u) {
+    const int idx = threadIdx.x + u * 512;
     const int r = idx >> 4, c = idx & 15;
-    v[t] = make_uint4(0, 0, 0, 0);
-    if (idx < NR * 16 && row0 + r < row_limit) v[t] = *reinterpret_cast<const uint4*>(g + (size_t)(row0 + r) * ld + c * 8);
+    t.v[u] = make_uint4(0, 0, 0, 0);
+    if (idx < NR * 16 && row0 + r < row_limit)
+      t.v[u] = *reinterpret_cast<const uint4*>(g + (size_t)(row0 + r) * ld + c * 8);
   }
+}
+template <bool ROPE, int NR>
+__device__ __forceinline__ void tile_commit(TileRegs<NR>& t, bf16_t* sR, int row0, int row_limit, const float* cs,
+                                            const float* sn) {
 #pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int idx = threadIdx.x + t * 512;
+  for (int u = 0; u < (NR * 16 + 511) / 512; ++u) {
+    const int idx = threadIdx.x + u * 512;
     const int r = idx >> 4, c = idx & 15;
     if (idx < NR * 16) {
       if (ROPE && row0 + r < row_limit)
-        v[t] = rope8(v[t], cs + (size_t)(row0 + r) * HP + 4 * c, sn + (size_t)(row0 + r) * HP + 4 * c);
-      *reinterpret_cast<uint4*>(sR + r * LDR + c * 8) = v[t];
+        t.v[u] = rope8(t.v[u], cs + (size_t)(row0 + r) * HP + 4 * c, sn + (size_t)(row0 + r) * HP + 4 * c);
+      *reinterpret_cast<uint4*>(sR + r * LDR + c * 8) = t.v[u];
     }
   }
 }
@@ -110,29 +115,49 @@ __device__ __forceinline__ uint4 frag_g(const bf16_t* g, size_t ld, int row, int
 // elements; lane 4q+p of the group supplies the address of row q, columns 4p..4p+3). For each of the 8
 // column blocks dt: f[dt] = { X[rb+4g+e][16dt+i] (e=0..3), X[rb+16+4g+e][16dt+i] (e=0..3) } — the k order of
 // pack_blocks. HI = false leaves the second half zero (16-row adapter block).
+struct TrRegs { uint2 lo[8], hi[8]; };
+// issue only (inline asm, invisible to the compiler's waitcnt pass): the reads return while other work runs
 template <bool HI>
-__device__ __forceinline__ void frags_tr_perm(const bf16_t* s, int rb, int lane, uint4 (&f)[8]) {
+__device__ __forceinline__ void tr_issue(const bf16_t* s, int rb, int lane, TrRegs& t) {
   const int g = lane >> 4, i = lane & 15;
   const bf16_t* a0 = s + (rb + 4 * g + (i >> 2)) * LDR + 4 * (i & 3);
   const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) bf16_t*)a0;
-  uint2 lo[8], hi[8];
-#define FVQA_TR(d)                                                                                       \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[d]) : "v"(addr), "i"(32 * d));            \
-  if (HI) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[d]) : "v"(addr), "i"(32 * d + 32 * LDR));
+#define FVQA_TR(d)                                                                                        \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.lo[d]) : "v"(addr), "i"(32 * d));           \
+  if (HI) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t.hi[d]) : "v"(addr), "i"(32 * d + 32 * LDR));
   FVQA_TR(0) FVQA_TR(1) FVQA_TR(2) FVQA_TR(3) FVQA_TR(4) FVQA_TR(5) FVQA_TR(6) FVQA_TR(7)
 #undef FVQA_TR
+}
+// wait for everything issued so far and assemble the 8 fragments
+template <bool HI>
+__device__ __forceinline__ void tr_collect(TrRegs& t, uint4 (&f)[8]) {
   if (HI) {
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
-                   "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]));
+                 : "+v"(t.lo[0]), "+v"(t.lo[1]), "+v"(t.lo[2]), "+v"(t.lo[3]), "+v"(t.lo[4]), "+v"(t.lo[5]),
+                   "+v"(t.lo[6]), "+v"(t.lo[7]), "+v"(t.hi[0]), "+v"(t.hi[1]), "+v"(t.hi[2]), "+v"(t.hi[3]),
+                   "+v"(t.hi[4]), "+v"(t.hi[5]), "+v"(t.hi[6]), "+v"(t.hi[7]));
 #pragma unroll
-    for (int d = 0; d < 8; ++d) f[d] = make_uint4(lo[d].x, lo[d].y, hi[d].x, hi[d].y);
+    for (int d = 0; d < 8; ++d) f[d] = make_uint4(t.lo[d].x, t.lo[d].y, t.hi[d].x, t.hi[d].y);
   } else {
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]));
+                 : "+v"(t.lo[0]), "+v"(t.lo[1]), "+v"(t.lo[2]), "+v"(t.lo[3]), "+v"(t.lo[4]), "+v"(t.lo[5]),
+                   "+v"(t.lo[6]), "+v"(t.lo[7]));
 #pragma unroll
-    for (int d = 0; d < 8; ++d) f[d] = make_uint4(lo[d].x, lo[d].y, 0u, 0u);
+    for (int d = 0; d < 8; ++d) f[d] = make_uint4(t.lo[d].x, t.lo[d].y, 0u, 0u);
   }
+}
+template <bool HI>
+__device__ __forceinline__ void frags_tr_perm(const bf16_t* s, int rb, int lane, uint4 (&f)[8]) {
+  TrRegs t;
+  tr_issue<HI>(s, rb, lane, t);
+  tr_collect<HI>(t, f);
+}
+// the 8 operand fragments (2 row blocks x 4 k-steps) of a 32-row group, all LDS reads issued together
+__device__ __forceinline__ void group_frags(const bf16_t* s, int rb, int lane, uint4 (&f)[2][4]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[c][ks] = frag(s, rb + 16 * c, 32 * ks, lane);
 }
 // 4 consecutive head dims of one row -> 8-byte store; INV: conjugate RoPE (pairs p0, p0+1 of the row's tables)
 template <bool INV>
@@ -169,7 +194,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
   bf16_t* sKa = sV + BQ * LDR;                            // [16][LDR]  adapter K rows (zero beyond A)
   bf16_t* sVa = sKa + 16 * LDR;                           // [16][LDR]  adapter V rows
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
   const size_t ld = (size_t)3 * D;
@@ -179,15 +204,24 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
   const int iqc = iq < S ? iq : S - 1;
   const float sc = rsqrtf((float)DH);
 
+  // every global load of the first key tile goes out before the first wait
   uint4 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    qf[ks] = frag_g(seq, ld, iqc, 32 * ks, lane);
-    if (ROPE) qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
-  }
+  TileRegs<16> rKa, rVa;
+  TileRegs<BQ> rK, rV;
   const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
-  stage_tile<false, 16>(sKa, arow + D, ld, 0, A, nullptr, nullptr);
-  stage_tile<false, 16>(sVa, arow + 2 * D, ld, 0, A, nullptr, nullptr);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = frag_g(seq, ld, iqc, 32 * ks, lane);
+  tile_load<16>(rKa, arow + D, ld, 0, A);
+  tile_load<16>(rVa, arow + 2 * D, ld, 0, A);
+  tile_load<BQ>(rK, seq + D, ld, 0, S);
+  tile_load<BQ>(rV, seq + 2 * D, ld, 0, S);
+  if (ROPE) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
+  }
+  tile_commit<false, 16>(rKa, sKa, 0, A, nullptr, nullptr);
+  tile_commit<false, 16>(rVa, sVa, 0, A, nullptr, nullptr);
 
   f32x4 oacc[8];
 #pragma unroll
@@ -198,19 +232,24 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
   const bool biased_row = vs >= 0 && iq >= vs + F;
 
   for (int kt = 0; kt <= qb; ++kt) {
-    __syncthreads();
-    stage_tile<ROPE, BQ>(sK, seq + D, ld, kt * BQ, S, cs, sn);
-    stage_tile<false, BQ>(sV, seq + 2 * D, ld, kt * BQ, S, nullptr, nullptr);
+    if (kt > 0) {
+      __syncthreads();                                    // tile kt-1 fully consumed
+      tile_load<BQ>(rK, seq + D, ld, kt * BQ, S);
+      tile_load<BQ>(rV, seq + 2 * D, ld, kt * BQ, S);
+    }
+    tile_commit<ROPE, BQ>(rK, sK, kt * BQ, S, cs, sn);
+    tile_commit<false, BQ>(rV, sV, kt * BQ, S, nullptr, nullptr);
     __syncthreads();
     const int jlast = min(i0 + 15, S - 1) - kt * BQ;      // last tile-local key any row of this wave sees
     const int ng = jlast < 0 ? 0 : min(4, (jlast >> 5) + 1);
     for (int gq = 0; gq < ng; ++gq) {                     // 32 keys = two 16-key score blocks = one P·V k-step
-      f32x4 st[2];
+      uint4 kfr[2][4];
+      group_frags(sK, 32 * gq, lane, kfr);
+      f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        st[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) st[c] = mma(frag(sK, 32 * gq + 16 * c, 32 * ks, lane), qf[ks], st[c]);
+      for (int ks = 0; ks < 4; ++ks) {
+        st[0] = mma(kfr[0][ks], qf[ks], st[0]);
+        st[1] = mma(kfr[1][ks], qf[ks], st[1]);
       }
       float v[2][4], mx = NEG_BIG;
 #pragma unroll
@@ -225,6 +264,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
           mx = fmaxf(mx, x);
         }
       mx = across_g_max(mx);
+      TrRegs tv;
+      tr_issue<true>(sV, 32 * gq, lane, tv);              // V fragments return under the exponentials
       const float mn = fmaxf(m, mx);
       const float alpha = __expf(m - mn);
       m = mn;
@@ -243,7 +284,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
         for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
       const uint4 pf = pack_blocks(p[0], p[1]);
       uint4 vf[8];
-      frags_tr_perm<true>(sV, 32 * gq, lane, vf);
+      tr_collect<true>(tv, vf);
 #pragma unroll
       for (int d = 0; d < 8; ++d) oacc[d] = mma(vf[d], pf, oacc[d]);
     }
@@ -314,7 +355,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   bf16_t* sVa = sKa + 16 * LDR;                           // [16][LDR]
   __shared__ float red[16];
   const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
   const size_t ld = (size_t)3 * D;
@@ -326,14 +367,27 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   const float sc = rsqrtf((float)DH);
   const size_t sbase = ((size_t)n * H + h) * S;
 
-  uint4 qf[4], dof[4];
-  float dtot = 0.f;                                       // dO·O over the row: this lane's 32 dims, then across g
+  // every global load of the first key tile goes out before the first wait
+  uint4 qf[4], dof[4], off[4];
+  TileRegs<16> rKa, rVa;
+  TileRegs<BQ> rK, rV;
+  const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     qf[ks] = frag_g(seq, ld, iqc, 32 * ks, lane);
-    if (ROPE) qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
     dof[ks] = frag_g(d_o + (size_t)n * S * D + h * DH, (size_t)D, iqc, 32 * ks, lane);
-    const uint4 of = frag_g(o + (size_t)n * S * D + h * DH, (size_t)D, iqc, 32 * ks, lane);
+    off[ks] = frag_g(o + (size_t)n * S * D + h * DH, (size_t)D, iqc, 32 * ks, lane);
+  }
+  const float lsa = lse_a[sbase + iqc], lst = lse_t[sbase + iqc];
+  tile_load<16>(rKa, arow + D, ld, 0, A);
+  tile_load<16>(rVa, arow + 2 * D, ld, 0, A);
+  tile_load<BQ>(rK, seq + D, ld, 0, S);
+  tile_load<BQ>(rV, seq + 2 * D, ld, 0, S);
+  float dtot = 0.f;                                       // dO·O over the row: this lane's 32 dims, then across g
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ROPE) qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
+    const uint4 of = off[ks];
     const unsigned tw[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w}, uw[4] = {of.x, of.y, of.z, of.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -341,7 +395,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
               __uint_as_float(tw[k] & 0xFFFF0000u) * __uint_as_float(uw[k] & 0xFFFF0000u);
   }
   dtot = across_g_sum(dtot);
-  const float lsa = lse_a[sbase + iqc], lst = lse_t[sbase + iqc];
   const float g1 = tanhf(gate1[h]);
   const float g2 = gate2[h];
   const int vs = vstart[n];
@@ -351,9 +404,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   for (int d = 0; d < 8; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- adapter block: dS_a, delta_a, d tanh-gate partial
-  const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
-  stage_tile<false, 16>(sKa, arow + D, ld, 0, A, nullptr, nullptr);
-  stage_tile<false, 16>(sVa, arow + 2 * D, ld, 0, A, nullptr, nullptr);
+  tile_commit<false, 16>(rKa, sKa, 0, A, nullptr, nullptr);
+  tile_commit<false, 16>(rVa, sVa, 0, A, nullptr, nullptr);
+  tile_commit<ROPE, BQ>(rK, sK, 0, S, cs, sn);
+  tile_commit<false, BQ>(rV, sV, 0, S, nullptr, nullptr);
   __syncthreads();
   float da, dg1 = 0.f, dg2 = 0.f;
   {
@@ -384,24 +438,31 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   const float dt = dtot - da;
 
   for (int kt = 0; kt <= qb; ++kt) {
-    __syncthreads();
-    stage_tile<ROPE, BQ>(sK, seq + D, ld, kt * BQ, S, cs, sn);
-    stage_tile<false, BQ>(sV, seq + 2 * D, ld, kt * BQ, S, nullptr, nullptr);
-    __syncthreads();
+    if (kt > 0) {
+      __syncthreads();                                    // tile kt-1 fully consumed
+      tile_load<BQ>(rK, seq + D, ld, kt * BQ, S);
+      tile_load<BQ>(rV, seq + 2 * D, ld, kt * BQ, S);
+      tile_commit<ROPE, BQ>(rK, sK, kt * BQ, S, cs, sn);
+      tile_commit<false, BQ>(rV, sV, kt * BQ, S, nullptr, nullptr);
+      __syncthreads();
+    }
     const int jlast = min(i0 + 15, S - 1) - kt * BQ;
     const int ng = jlast < 0 ? 0 : min(4, (jlast >> 5) + 1);
     for (int gq = 0; gq < ng; ++gq) {
-      f32x4 st[2], dpt[2];
+      uint4 kfr[2][4], vfr[2][4];
+      group_frags(sK, 32 * gq, lane, kfr);
+      group_frags(sV, 32 * gq, lane, vfr);
+      f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dpt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        st[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dpt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          st[c] = mma(frag(sK, 32 * gq + 16 * c, 32 * ks, lane), qf[ks], st[c]);
-          dpt[c] = mma(frag(sV, 32 * gq + 16 * c, 32 * ks, lane), dof[ks], dpt[c]);
-        }
+      for (int ks = 0; ks < 4; ++ks) {                    // four independent accumulation chains
+        st[0] = mma(kfr[0][ks], qf[ks], st[0]);
+        st[1] = mma(kfr[1][ks], qf[ks], st[1]);
+        dpt[0] = mma(vfr[0][ks], dof[ks], dpt[0]);
+        dpt[1] = mma(vfr[1][ks], dof[ks], dpt[1]);
       }
+      TrRegs tk;
+      tr_issue<true>(sK, 32 * gq, lane, tk);              // Kᵀ fragments return under the exponentials
       float ds[2][4];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -417,7 +478,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
         }
       const uint4 sf = pack_blocks(ds[0], ds[1]);
       uint4 kf8[8];
-      frags_tr_perm<true>(sK, 32 * gq, lane, kf8);
+      tr_collect<true>(tk, kf8);
 #pragma unroll
       for (int d = 0; d < 8; ++d) dq[d] = mma(kf8[d], sf, dq[d]);
     }
@@ -462,7 +523,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   float* sDl = sL + BQ;
   const int kb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
   const bool adapter = kb == nkb;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
   const size_t ld = (size_t)3 * D;
@@ -481,31 +542,52 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   const int jk = j0 + li;
   const int limit = adapter ? A : S;
   const bool kok = jk < limit;
+  // every global load of the first query tile goes out before the first wait
   uint4 kf[4], vf[4];
+  TileRegs<BQ> rQ, rdO;
+  const int t_first = adapter ? 0 : kb;
+  const int jc = kok ? jk : limit - 1;
   {
     const bf16_t* kbase = adapter ? qkv + (size_t)n_seq * S * ld + h * DH : seq;
-    const int jc = kok ? jk : limit - 1;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       kf[ks] = frag_g(kbase + D, ld, jc, 32 * ks, lane);
-      if (ROPE && !adapter)
-        kf[ks] = rope8(kf[ks], cs + (size_t)jc * HP + 16 * ks + 4 * g, sn + (size_t)jc * HP + 16 * ks + 4 * g);
       vf[ks] = frag_g(kbase + 2 * D, ld, jc, 32 * ks, lane);
-      if (!kok) { kf[ks] = make_uint4(0, 0, 0, 0); vf[ks] = make_uint4(0, 0, 0, 0); }
     }
+  }
+  tile_load<BQ>(rQ, seq, ld, t_first * BQ, S);
+  tile_load<BQ>(rdO, dob, (size_t)D, t_first * BQ, S);
+  float l_in = 0.f, d_in = 0.f;
+  if (threadIdx.x < BQ) {
+    const int ii = min(t_first * BQ + (int)threadIdx.x, S - 1);
+    l_in = adapter ? lse_a[sbase + ii] : lse_t[sbase + ii];
+    d_in = adapter ? delta_a[sbase + ii] : delta_t[sbase + ii];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ROPE && !adapter)
+      kf[ks] = rope8(kf[ks], cs + (size_t)jc * HP + 16 * ks + 4 * g, sn + (size_t)jc * HP + 16 * ks + 4 * g);
+    if (!kok) { kf[ks] = make_uint4(0, 0, 0, 0); vf[ks] = make_uint4(0, 0, 0, 0); }
   }
   const int vs = vstart[n];
   const float g2 = gate2[h];
   const bool win_key = vs >= 0 && jk >= vs && jk < vs + F;
-  const int t_first = adapter ? 0 : kb;
   for (int t = t_first; t < nqt; ++t) {
-    __syncthreads();
-    stage_tile<ROPE, BQ>(sQ, seq, ld, t * BQ, S, cs, sn);
-    stage_tile<false, BQ>(sdO, dob, (size_t)D, t * BQ, S, nullptr, nullptr);
+    if (t > t_first) {
+      __syncthreads();                                    // tile t-1 fully consumed
+      tile_load<BQ>(rQ, seq, ld, t * BQ, S);
+      tile_load<BQ>(rdO, dob, (size_t)D, t * BQ, S);
+      if (threadIdx.x < BQ) {
+        const int ii = min(t * BQ + (int)threadIdx.x, S - 1);
+        l_in = adapter ? lse_a[sbase + ii] : lse_t[sbase + ii];
+        d_in = adapter ? delta_a[sbase + ii] : delta_t[sbase + ii];
+      }
+    }
+    tile_commit<ROPE, BQ>(rQ, sQ, t * BQ, S, cs, sn);
+    tile_commit<false, BQ>(rdO, sdO, t * BQ, S, nullptr, nullptr);
     if (threadIdx.x < BQ) {
-      const int ii = min(t * BQ + (int)threadIdx.x, S - 1);
-      sL[threadIdx.x] = adapter ? lse_a[sbase + ii] : lse_t[sbase + ii];
-      sDl[threadIdx.x] = adapter ? delta_a[sbase + ii] : delta_t[sbase + ii];
+      sL[threadIdx.x] = l_in;
+      sDl[threadIdx.x] = d_in;
     }
     __syncthreads();
     // 32-query groups of this tile that this wave works on
@@ -514,17 +596,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
     if (adapter) { gbeg = w; gend = w < 4 ? gmax : 0; gstep = 4; }
     else { gbeg = (t == kb) ? (w >> 1) : 0; gend = gmax; gstep = 1; }
     for (int gq = gbeg; gq < gend; gq += gstep) {
-      f32x4 s[2], dp[2];
+      uint4 qfr[2][4], ofr[2][4];
+      group_frags(sQ, 32 * gq, lane, qfr);
+      group_frags(sdO, 32 * gq, lane, ofr);
+      f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s[c] = mma(frag(sQ, 32 * gq + 16 * c, 32 * ks, lane), kf[ks], s[c]);
-          dp[c] = mma(frag(sdO, 32 * gq + 16 * c, 32 * ks, lane), vf[ks], dp[c]);
-        }
+      for (int ks = 0; ks < 4; ++ks) {                    // four independent accumulation chains
+        s[0] = mma(qfr[0][ks], kf[ks], s[0]);
+        s[1] = mma(qfr[1][ks], kf[ks], s[1]);
+        dp[0] = mma(ofr[0][ks], vf[ks], dp[0]);
+        dp[1] = mma(ofr[1][ks], vf[ks], dp[1]);
       }
+      TrRegs to, tq;
+      tr_issue<true>(sdO, 32 * gq, lane, to);             // dOᵀ / Qᵀ fragments return under the exponentials
+      tr_issue<true>(sQ, 32 * gq, lane, tq);
       float p[2][4], ds[2][4];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -549,10 +635,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
       const uint4 pf = pack_blocks(p[0], p[1]);
       const uint4 sf = pack_blocks(ds[0], ds[1]);
       uint4 t8[8];
-      frags_tr_perm<true>(sdO, 32 * gq, lane, t8);
+      tr_collect<true>(to, t8);                           // waits for both sets (in-order return)
 #pragma unroll
       for (int d = 0; d < 8; ++d) dv[d] = mma(t8[d], pf, dv[d]);
-      frags_tr_perm<true>(sQ, 32 * gq, lane, t8);
+      tr_collect<true>(tq, t8);
 #pragma unroll
       for (int d = 0; d < 8; ++d) dk[d] = mma(t8[d], sf, dk[d]);
     }
@@ -600,7 +686,394 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   }
 }
 
+
+// ------------------------------------------------------------------------------- backward, S <= 128: one kernel
+// One workgroup per (sequence, head) keeps Q, K, V, dO of the whole sequence in LDS (4 x 34 KiB) and runs the
+// three passes back to back: (A) wave = 16 queries -> dQ, row deltas; (B) wave = 16 keys -> dK, dV; (C) waves 4-7
+// -> the adapter keys' dK, dV (one 32-query group each, summed through LDS into this sequence's fp32 partial).
+// The batch reduction of the adapter partials and of the gate sums is done by the LAST workgroup of each head to
+// arrive (integer arrival counter in the workspace, self-resetting; partials are summed in sequence order, so the
+// result does not depend on which workgroup is last): no separate reduction launch.
+template <bool ROPE>
+__global__ __launch_bounds__(512) void attn_bwd_fused_k(
+    const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+    const float* __restrict__ lse_a, const float* __restrict__ lse_t, const float* __restrict__ gate1,
+    const float* __restrict__ gate2, const int32_t* __restrict__ vstart, const float* __restrict__ cs,
+    const float* __restrict__ sn, bf16_t* __restrict__ dqkv, float* __restrict__ dgate1, float* __restrict__ dgate2,
+    float* gate_part, float* dka_part, float* dva_part, int* arrive,
+    int n_seq, int S, int H, int A, int F) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* sQ = reinterpret_cast<bf16_t*>(smem_raw);      // [BQ][LDR] rotated Q
+  bf16_t* sK = sQ + BQ * LDR;                             // [BQ][LDR] rotated K
+  bf16_t* sV = sK + BQ * LDR;
+  bf16_t* sdO = sV + BQ * LDR;
+  bf16_t* sKa = sdO + BQ * LDR;                           // [16][LDR]
+  bf16_t* sVa = sKa + 16 * LDR;
+  float* sLt = reinterpret_cast<float*>(sVa + 16 * LDR);  // [BQ] lse of the causal softmax, adapter softmax,
+  float* sLa = sLt + BQ;                                  //      then the row deltas written by pass A
+  float* sDt = sLa + BQ;
+  float* sDa = sDt + BQ;
+  __shared__ float red[16];
+  __shared__ int last_flag;
+  const int h = blockIdx.x, n = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int D = H * DH;
+  const size_t ld = (size_t)3 * D;
+  const bf16_t* seq = qkv + (size_t)n * S * ld + h * DH;
+  const bf16_t* dob = d_o + (size_t)n * S * D + h * DH;
+  const bf16_t* arow = qkv + (size_t)n_seq * S * ld + h * DH;
+  const float sc = rsqrtf((float)DH);
+  const size_t sbase = ((size_t)n * H + h) * S;
+  const int r16 = w * 16 + li;                            // this lane's query (pass A) / key (pass B)
+  const int r16c = r16 < S ? r16 : S - 1;
+  const bool live = r16 < S;
+  const int gmax = min(4, (S + 31) >> 5);                 // 32-row groups holding real rows
+
+  // ---- pass 0: every global load in flight, then rotate + stage
+  {
+    TileRegs<BQ> rQ, rK, rV, rdO;
+    TileRegs<16> rKa, rVa;
+    tile_load<BQ>(rQ, seq, ld, 0, S);
+    tile_load<BQ>(rK, seq + D, ld, 0, S);
+    tile_load<BQ>(rV, seq + 2 * D, ld, 0, S);
+    tile_load<BQ>(rdO, dob, (size_t)D, 0, S);
+    tile_load<16>(rKa, arow + D, ld, 0, A);
+    tile_load<16>(rVa, arow + 2 * D, ld, 0, A);
+    float lt_in = 0.f, la_in = 0.f;
+    if (threadIdx.x < BQ) {
+      const int ii = min((int)threadIdx.x, S - 1);
+      lt_in = lse_t[sbase + ii];
+      la_in = lse_a[sbase + ii];
+    }
+    tile_commit<ROPE, BQ>(rQ, sQ, 0, S, cs, sn);
+    tile_commit<ROPE, BQ>(rK, sK, 0, S, cs, sn);
+    tile_commit<false, BQ>(rV, sV, 0, S, nullptr, nullptr);
+    tile_commit<false, BQ>(rdO, sdO, 0, S, nullptr, nullptr);
+    tile_commit<false, 16>(rKa, sKa, 0, A, nullptr, nullptr);
+    tile_commit<false, 16>(rVa, sVa, 0, A, nullptr, nullptr);
+    if (threadIdx.x < BQ) {
+      sLt[threadIdx.x] = lt_in;
+      sLa[threadIdx.x] = la_in;
+    }
+  }
+  uint4 off[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) off[ks] = frag_g(o + (size_t)n * S * D + h * DH, (size_t)D, r16c, 32 * ks, lane);
+  const float g1 = tanhf(gate1[h]);
+  const float g2 = gate2[h];
+  const int vs = vstart[n];
+  __syncthreads();
+
+  float dg1 = 0.f, dg2 = 0.f;
+  // ---- pass A: dQ of queries 16w..16w+15 (this lane: query r16, score-block column)
+  {
+    uint4 qf[4], dof[4];
+    float dtot = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = frag(sQ, 16 * w, 32 * ks, lane);
+      dof[ks] = frag(sdO, 16 * w, 32 * ks, lane);
+      const unsigned tw[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w};
+      const unsigned uw[4] = {off[ks].x, off[ks].y, off[ks].z, off[ks].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        dtot += __uint_as_float(tw[k] << 16) * __uint_as_float(uw[k] << 16) +
+                __uint_as_float(tw[k] & 0xFFFF0000u) * __uint_as_float(uw[k] & 0xFFFF0000u);
+    }
+    dtot = across_g_sum(dtot);
+    const float lsa = sLa[r16], lst = sLt[r16];
+    const bool biased_row = vs >= 0 && r16 >= vs + F;
+    f32x4 dq[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float da;
+    {
+      f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dpa = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sa = mma(frag(sKa, 0, 32 * ks, lane), qf[ks], sa);
+        dpa = mma(frag(sVa, 0, 32 * ks, lane), dof[ks], dpa);
+      }
+      float pa[4], dov[4], part = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = 4 * g + r < A;
+        pa[r] = ok ? __expf(sa[r] * sc - lsa) : 0.f;
+        dov[r] = ok ? dpa[r] : 0.f;
+        if (live) dg1 += dov[r] * pa[r];
+        part += pa[r] * g1 * dov[r];
+      }
+      da = across_g_sum(part);
+      const float ds[4] = {pa[0] * (g1 * dov[0] - da), pa[1] * (g1 * dov[1] - da), pa[2] * (g1 * dov[2] - da),
+                           pa[3] * (g1 * dov[3] - da)};
+      const uint4 sf = make_uint4(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]), 0u, 0u);
+      uint4 kf8[8];
+      frags_tr_perm<false>(sKa, 0, lane, kf8);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) dq[d] = mma(kf8[d], sf, dq[d]);
+    }
+    const float dt = dtot - da;
+    const int ng = min(gmax, (w >> 1) + 1);               // keys 0 .. 16w+15
+    for (int gq = 0; gq < ng; ++gq) {
+      uint4 kfr[2][4], vfr[2][4];
+      group_frags(sK, 32 * gq, lane, kfr);
+      group_frags(sV, 32 * gq, lane, vfr);
+      f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dpt[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                    // four independent accumulation chains
+        st[0] = mma(kfr[0][ks], qf[ks], st[0]);
+        st[1] = mma(kfr[1][ks], qf[ks], st[1]);
+        dpt[0] = mma(vfr[0][ks], dof[ks], dpt[0]);
+        dpt[1] = mma(vfr[1][ks], dof[ks], dpt[1]);
+      }
+      TrRegs tk;
+      tr_issue<true>(sK, 32 * gq, lane, tk);              // Kᵀ fragments return under the exponentials
+      float ds[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 32 * gq + 16 * c + 4 * g + r;
+          float x = st[c][r] * sc;
+          const bool inwin = biased_row && j >= vs && j < vs + F;
+          if (inwin) x += g2;
+          const float p = (j <= r16 && j < S && live) ? __expf(x - lst) : 0.f;
+          ds[c][r] = p * (dpt[c][r] - dt);
+          if (inwin) dg2 += ds[c][r];
+        }
+      const uint4 sf = pack_blocks(ds[0], ds[1]);
+      uint4 kf8[8];
+      tr_collect<true>(tk, kf8);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) dq[d] = mma(kf8[d], sf, dq[d]);
+    }
+    if (live) {
+      bf16_t* row = dqkv + ((size_t)n * S + r16) * ld + h * DH + 4 * g;
+      const float* cr = ROPE ? cs + (size_t)r16 * HP + 2 * g : nullptr;
+      const float* sr = ROPE ? sn + (size_t)r16 * HP + 2 * g : nullptr;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float x[4] = {dq[d][0] * sc, dq[d][1] * sc, dq[d][2] * sc, dq[d][3] * sc};
+        store4<ROPE>(row + 16 * d, x, cr + 8 * d, sr + 8 * d);
+      }
+    }
+    if (g == 0) {
+      sDa[r16] = da;
+      sDt[r16] = dt;
+    }
+  }
+  __syncthreads();
+
+  // ---- pass B: dK, dV of keys 16w..16w+15 (this lane: key r16; rows >= S are zero in LDS)
+  f32x4 dk[8], dv[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  {
+    uint4 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag(sK, 16 * w, 32 * ks, lane);
+      vf[ks] = frag(sV, 16 * w, 32 * ks, lane);
+    }
+    const bool win_key = vs >= 0 && r16 >= vs && r16 < vs + F;
+    for (int gq = w >> 1; gq < gmax; ++gq) {
+      uint4 qfr[2][4], ofr[2][4];
+      group_frags(sQ, 32 * gq, lane, qfr);
+      group_frags(sdO, 32 * gq, lane, ofr);
+      f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                    // four independent accumulation chains
+        s[0] = mma(qfr[0][ks], kf[ks], s[0]);
+        s[1] = mma(qfr[1][ks], kf[ks], s[1]);
+        dp[0] = mma(ofr[0][ks], vf[ks], dp[0]);
+        dp[1] = mma(ofr[1][ks], vf[ks], dp[1]);
+      }
+      TrRegs to, tq;
+      tr_issue<true>(sdO, 32 * gq, lane, to);             // dOᵀ / Qᵀ fragments return under the exponentials
+      tr_issue<true>(sQ, 32 * gq, lane, tq);
+      float p[2][4], ds[2][4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(sLt + 32 * gq + 16 * c + 4 * g);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sDt + 32 * gq + 16 * c + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 32 * gq + 16 * c + 4 * g + r;
+          float x = s[c][r] * sc;
+          if (win_key && i >= vs + F) x += g2;
+          const float pp = (r16 <= i && i < S && live) ? __expf(x - lse4[r]) : 0.f;
+          ds[c][r] = pp * (dp[c][r] - dl4[r]);
+          p[c][r] = pp;
+        }
+      }
+      const uint4 pf = pack_blocks(p[0], p[1]);
+      const uint4 sf = pack_blocks(ds[0], ds[1]);
+      uint4 t8[8];
+      tr_collect<true>(to, t8);                           // waits for both sets (in-order return)
+#pragma unroll
+      for (int d = 0; d < 8; ++d) dv[d] = mma(t8[d], pf, dv[d]);
+      tr_collect<true>(tq, t8);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) dk[d] = mma(t8[d], sf, dk[d]);
+    }
+    if (live) {
+      bf16_t* row = dqkv + ((size_t)n * S + r16) * ld + h * DH + 4 * g;
+      const float* cr = ROPE ? cs + (size_t)r16 * HP + 2 * g : nullptr;
+      const float* sr = ROPE ? sn + (size_t)r16 * HP + 2 * g : nullptr;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float xk[4] = {dk[d][0] * sc, dk[d][1] * sc, dk[d][2] * sc, dk[d][3] * sc};
+        const float xv[4] = {dv[d][0], dv[d][1], dv[d][2], dv[d][3]};
+        store4<ROPE>(row + D + 16 * d, xk, cr + 8 * d, sr + 8 * d);
+        store4<false>(row + 2 * D + 16 * d, xv, nullptr, nullptr);
+      }
+    }
+  }
+
+  // ---- pass C: adapter keys (this lane: adapter row li), waves 4-7 take query group w-4
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (w >= 4 && w - 4 < gmax) {
+    const int gq = w - 4;
+    const bool aok = li < A;
+    uint4 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = frag(sKa, 0, 32 * ks, lane);
+      vf[ks] = frag(sVa, 0, 32 * ks, lane);
+    }
+    uint4 qfr[2][4], ofr[2][4];
+    group_frags(sQ, 32 * gq, lane, qfr);
+    group_frags(sdO, 32 * gq, lane, ofr);
+    f32x4 s[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 dp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s[0] = mma(qfr[0][ks], kf[ks], s[0]);
+      s[1] = mma(qfr[1][ks], kf[ks], s[1]);
+      dp[0] = mma(ofr[0][ks], vf[ks], dp[0]);
+      dp[1] = mma(ofr[1][ks], vf[ks], dp[1]);
+    }
+    TrRegs to, tq;
+    tr_issue<true>(sdO, 32 * gq, lane, to);
+    tr_issue<true>(sQ, 32 * gq, lane, tq);
+    float p[2][4], ds[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const f32x4 lse4 = *reinterpret_cast<const f32x4*>(sLa + 32 * gq + 16 * c + 4 * g);
+      const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sDa + 32 * gq + 16 * c + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 32 * gq + 16 * c + 4 * g + r;
+        const float pp = (aok && i < S) ? __expf(s[c][r] * sc - lse4[r]) : 0.f;
+        ds[c][r] = pp * (g1 * dp[c][r] - dl4[r]);
+        p[c][r] = pp * g1;
+      }
+    }
+    const uint4 pf = pack_blocks(p[0], p[1]);
+    const uint4 sf = pack_blocks(ds[0], ds[1]);
+    uint4 t8[8];
+    tr_collect<true>(to, t8);                           // waits for both sets (in-order return)
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dv[d] = mma(t8[d], pf, dv[d]);
+    tr_collect<true>(tq, t8);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dk[d] = mma(t8[d], sf, dk[d]);
+  }
+  __syncthreads();                                        // pass B is done with sK / sV: reuse them
+  float* rK = reinterpret_cast<float*>(sK);               // [4][16][DH] fp32 (32 KiB <= one tile)
+  float* rV = reinterpret_cast<float*>(sV);
+  if (w >= 4) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      *reinterpret_cast<f32x4*>(rK + ((w - 4) * 16 + li) * DH + 16 * d + 4 * g) =
+          f32x4{dk[d][0] * sc, dk[d][1] * sc, dk[d][2] * sc, dk[d][3] * sc};
+      *reinterpret_cast<f32x4*>(rV + ((w - 4) * 16 + li) * DH + 16 * d + 4 * g) = dv[d];
+    }
+  }
+  __syncthreads();
+  // Batch reduction by the LAST workgroup of this head to arrive. Cross-XCD visibility without a device-scope
+  // fence (it writes back / scans the whole L2 on this multi-XCD part: measured +36 us per launch):
+  //  * the partials are WRITTEN with device-scope relaxed atomic stores (sc1: written through to memory);
+  //    every thread waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0)), the barrier
+  //    collects the workgroup, and only then one thread bumps the arrival counter (device-scope RMW);
+  //  * the adapter partials are READ with ordinary (pipelined) loads: each 128-byte line of them is written
+  //    whole by ONE workgroup and read by nobody before this point of the launch, so the reader's L1/L2 hold
+  //    no older copy (a copy in its L2 can only come from a same-XCD writer and is current); device-scope
+  //    loads of lines just written through measured 40 us slower;
+  //  * the gate partials share lines between heads, so they are read with device-scope (sc1) loads.
+  for (int idx = threadIdx.x; idx < A * DH; idx += 512) {
+    const int aa = idx / DH, d = idx % DH;
+    float sk = 0.f, sv = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      sk += rK[(ww * 16 + aa) * DH + d];
+      sv += rV[(ww * 16 + aa) * DH + d];
+    }
+    const size_t oidx = ((size_t)n * A + aa) * D + h * DH + d;
+    __hip_atomic_store(dka_part + oidx, sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dva_part + oidx, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const float b1 = block_sum_512(dg1, red);
+  const float b2 = block_sum_512(dg2, red + 8);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(gate_part + ((size_t)n * H + h) * 2, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(gate_part + ((size_t)n * H + h) * 2 + 1, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(arrive + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (old == n_seq - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  for (int idx = threadIdx.x; idx < A * DH; idx += 512) {
+    const int aa = idx / DH, d = idx % DH;
+    float sk = 0.f, sv = 0.f;
+    for (int n0 = 0; n0 < n_seq; n0 += 8) {               // 16 coherent loads in flight, summed in sequence order
+      float tk[8], tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int nn = min(n0 + u, n_seq - 1);
+        const size_t pi = ((size_t)nn * A + aa) * D + h * DH + d;
+        tk[u] = dka_part[pi];
+        tv[u] = dva_part[pi];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (n0 + u < n_seq) { sk += tk[u]; sv += tv[u]; }
+    }
+    bf16_t* row = dqkv + ((size_t)n_seq * S + aa) * ld + h * DH + d;
+    row[0] = __float2bfloat16(0.f);
+    row[D] = __float2bfloat16(sk);
+    row[2 * D] = __float2bfloat16(sv);
+  }
+  // gate sums: one coherent load per thread (all in flight together), then a fixed-order sum by thread 0
+  float s1 = 0.f, s2 = 0.f;
+  for (int n0 = 0; n0 < n_seq; n0 += BQ) {
+    __syncthreads();
+    if ((int)threadIdx.x < min(BQ, n_seq - n0)) {
+      const size_t gi = ((size_t)(n0 + threadIdx.x) * H + h) * 2;
+      sLt[threadIdx.x] = __hip_atomic_load(gate_part + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sLa[threadIdx.x] = __hip_atomic_load(gate_part + gi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int u = 0; u < min(BQ, n_seq - n0); ++u) { s1 += sLt[u]; s2 += sLa[u]; }
+  }
+  if (threadIdx.x == 0) {
+    dgate1[h] += s1 * (1.f - g1 * g1);
+    dgate2[h] += s2;
+    __hip_atomic_store(arrive + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 constexpr size_t FWD_LDS = (size_t)(2 * BQ + 32) * LDR * 2;
+constexpr size_t FUSED_LDS = (size_t)(4 * BQ + 32) * LDR * 2 + 4 * BQ * 4;
 constexpr size_t DKV_LDS = (size_t)2 * BQ * LDR * 2 + 2 * BQ * 4;
 static_assert(DKV_LDS >= (size_t)2 * 4 * 16 * DH * 4, "adapter reduction reuses the staging area");
 
@@ -634,10 +1107,13 @@ int fvqa_attn_fwd_mfma(const void* qkv, void* o, float* lse_a, float* lse_t, con
   return 0;
 }
 
+// Returns 1 when the batch reduction (adapter rows of dqkv, dgate1/dgate2) has been done by the launch itself
+// (S <= 128: fused kernel), 0 when the caller still has to run attn_bwd_reduce_k over nqb = fvqa_attn_mfma_qblocks(S).
 int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const float* lse_a, const float* lse_t,
                        const float* gate1, const float* gate2, const int32_t* vstart, const float* cos_t,
-                       const float* sin_t, void* dqkv, float* delta_a, float* delta_t, float* gate_part, float* dka,
-                       float* dva, int n_seq, int S, int H, int A, int F, hipStream_t st) {
+                       const float* sin_t, void* dqkv, float* dgate1, float* dgate2, float* delta_a, float* delta_t,
+                       float* gate_part, float* dka, float* dva, int* arrive, int n_seq, int S, int H, int A, int F,
+                       hipStream_t st) {
   const int nqb = fvqa_attn_mfma_qblocks(S);
   static bool attr = false;
   if (!attr) {
@@ -645,7 +1121,19 @@ int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const fl
     allow_lds(attn_bwd_dq_mfma_k<false>, FWD_LDS);
     allow_lds(attn_bwd_dkv_mfma_k<true>, DKV_LDS);
     allow_lds(attn_bwd_dkv_mfma_k<false>, DKV_LDS);
+    allow_lds(attn_bwd_fused_k<true>, FUSED_LDS);
+    allow_lds(attn_bwd_fused_k<false>, FUSED_LDS);
     attr = true;
+  }
+  static const bool no_fuse = [] { const char* e = getenv("FVQA_ATTN_BWD_SPLIT"); return e && e[0] == '1'; }();
+  if (nqb == 1 && !no_fuse) {
+#define FVQA_FUSED(R)                                                                                                 \
+  hipLaunchKernelGGL(attn_bwd_fused_k<R>, dim3(H, n_seq), dim3(512), FUSED_LDS, st, (const bf16_t*)d_o,                \
+                     (const bf16_t*)qkv, (const bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t,          \
+                     (bf16_t*)dqkv, dgate1, dgate2, gate_part, dka, dva, arrive, n_seq, S, H, A, F);
+    if (cos_t) { FVQA_FUSED(true) } else { FVQA_FUSED(false) }
+#undef FVQA_FUSED
+    return 1;
   }
 #define FVQA_BWD(R)                                                                                                   \
   hipLaunchKernelGGL(attn_bwd_dq_mfma_k<R>, dim3(nqb, H, n_seq), dim3(512), FWD_LDS, st, (const bf16_t*)d_o,           \

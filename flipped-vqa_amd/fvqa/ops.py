@@ -334,6 +334,8 @@ def attn_bwd_workspace(n_seq, S, H, Dh, A) -> int:
 
 def attn_bwd(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace,
              n_seq, S, H, Dh, A, F, rope=None):
+    """`workspace`: attn_bwd_workspace(...) bytes, ZEROED once when allocated (its head holds the fused
+    kernel's arrival counters, which every call leaves at zero again)."""
     _dev(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace)
     cos_t, sin_t = _rope_tables(rope, S, Dh, "attn_bwd")
     D = _attn_shapes(qkv, n_seq, S, H, Dh, A)

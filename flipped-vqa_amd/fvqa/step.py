@@ -113,7 +113,7 @@ class Arena:
         self.d_qav = e(eng_frames(c, n_seq), D, dtype=f32)
         self.gscale = e(3, dtype=f32)
         ws = ops.attn_bwd_workspace(n_seq, S, H, c.Dh, A)
-        self.attn_ws = torch.empty(ws, dtype=torch.uint8, device=dev)
+        self.attn_ws = torch.zeros(ws, dtype=torch.uint8, device=dev)   # arrival counters start at zero
 
 
 def eng_frames(c, n_seq):

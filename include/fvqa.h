@@ -121,7 +121,9 @@ int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const fl
                   int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
                   int dtype, void* stream);
 /* workspace bytes fvqa_attn_bwd needs (fp32 partials for the batch-summed adapter k/v
- * gradients and the per-head gate sums) */
+ * gradients and the per-head gate sums). Its FIRST 1024 BYTES are integer arrival counters of the
+ * fused bf16 backward: the caller zeroes them once after allocating the workspace; every call
+ * leaves them zero again. One workspace serves one stream at a time. */
 size_t fvqa_attn_bwd_workspace(int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len);
 /* dqkv: (n_seq*S + A, 3*dim): dq,dk,dv for sequence rows; adapter rows get [0, dK_a, dV_a] summed over
  * sequences. With cos_t/sin_t == NULL, qkv holds rotated q,k and dq,dk come out NOT yet un-rotated

@@ -280,7 +280,7 @@ def test_attention_fwd_bwd(dtype, N, S, H, vstart):
     dqkv = torch.full((N * S + A, 3 * D), float("nan"), dtype=dtype, device=DEV)
     dg1d = torch.ones(H, dtype=torch.float32, device=DEV)          # kernels accumulate into these
     dg2d = torch.ones(H, dtype=torch.float32, device=DEV)
-    ws = torch.empty(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
     # the backward consumes the forward's own (storage-rounded) o
     ops.attn_bwd(dev(d_o), qkv_d, o, lse_a, lse_t, g1d, g2d, vsd, dqkv, dg1d, dg2d, ws, N, S, H, Dh, A, F)
     t = tol(dtype, 5e-5, 2e-2)
@@ -317,7 +317,7 @@ def test_attention_fused_rope_bf16(N, S, H, vstart):
         lt = torch.empty_like(la)
         dqkv = torch.full((N * S + A, 3 * D), float("nan"), dtype=dtype, device=DEV)
         dg1, dg2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
-        ws = torch.empty(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
+        ws = torch.zeros(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
         rope = (cd, sd) if fused else None
         if not fused:
             ops.rope_qk(buf, cd, sd, N, S, H, Dh)
@@ -380,7 +380,7 @@ def test_attention_is_deterministic():
         ops.attn_fwd(dev(qkv), o, la, lt, dev(g1), dev(g2), dev(vs), N, S, H, Dh, A, F)
         dqkv = torch.empty(N * S + A, 3 * D, device=DEV)
         dg1, dg2 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
-        ws = torch.empty(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
+        ws = torch.zeros(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
         ops.attn_bwd(o.clone(), dev(qkv), o, la, lt, dev(g1), dev(g2), dev(vs), dqkv, dg1, dg2, ws, N, S, H, Dh, A, F)
         outs.append((o.cpu(), dqkv.cpu(), dg1.cpu(), dg2.cpu()))
     for a, b in zip(*outs):

@@ -1,0 +1,167 @@
+"""Device-side half of the batch producer: collated CPU batches -> batches resident in HBM
+without ever stalling the training stream.
+
+The reference moves each field with its own blocking `.cuda()` inside forward (llama/model.py:255-264: ~8
+pageable copies per step on the compute stream). Here a background thread packs every tensor the step reads
+into ONE pinned staging buffer per slot, one asynchronous H2D copy per batch runs on a side stream, and the
+consumer gets views of the slot's device buffer after a stream-side event wait (no host synchronisation).
+`depth` slots are in flight; a slot is refilled only after the step that consumed it has been passed by the
+compute stream. Host integers (`video_start`, `prefix_index`) stay Python lists, as the model reads them.
+On a CPU device the same packing runs without pinning and streams (used by the CPU tests)."""
+from __future__ import annotations
+
+import math
+import queue
+import threading
+from typing import Dict, Iterable, Iterator, List, Optional, Tuple
+
+import torch
+
+_ALIGN = 256
+TENSOR_FIELDS = ("text_id", "label", "video_index", "label_mask")     # dicts over tasks
+PLAIN_FIELDS = ("video", "video_len", "answer", "qtype")              # plain tensors
+HOST_FIELDS = ("video_start", "prefix_index", "vid", "text", "qid")   # stay on the host
+
+
+def _tensor_items(batch: dict) -> List[Tuple[Tuple[str, Optional[str]], torch.Tensor]]:
+    items = []
+    for f in PLAIN_FIELDS:
+        if f in batch and torch.is_tensor(batch[f]):
+            items.append(((f, None), batch[f]))
+    for f in TENSOR_FIELDS:
+        if f in batch:
+            for t, v in batch[f].items():
+                if torch.is_tensor(v):
+                    items.append(((f, t), v))
+    return items
+
+
+class _Slot:
+    def __init__(self, nbytes: int, device: torch.device):
+        cuda = device.type == "cuda"
+        self.host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=cuda)
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device) if cuda else self.host
+        self.copied = torch.cuda.Event() if cuda else None       # H2D of this slot finished
+        self.released = torch.cuda.Event() if cuda else None     # compute stream is past the consumer step
+        self.in_use = False
+
+
+class DeviceBatchProducer:
+    def __init__(self, loader: Iterable[dict], device, depth: int = 2):
+        self.loader = loader
+        self.device = torch.device(device)
+        self.depth = max(2, int(depth))
+        self.cuda = self.device.type == "cuda"
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._slots: List[_Slot] = []
+        self._layout = None            # [(key, dtype, per-sample shape, offset, max bytes)], total
+        self._max_b = 0
+        self.h2d_bytes = 0
+
+    def __len__(self):
+        return len(self.loader)
+
+    # ------------------------------------------------------------------ layout
+    def _make_layout(self, batch: dict):
+        off, lay = 0, []
+        self._max_b = int(batch["video"].shape[0]) if "video" in batch else \
+            int(next(iter(batch["text_id"].values())).shape[0])
+        for key, v in _tensor_items(batch):
+            nbytes = v.numel() * v.element_size()
+            lay.append((key, v.dtype, tuple(v.shape[1:]), off, nbytes))
+            off += (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        self._layout = (lay, max(off, _ALIGN))
+        self._slots = [_Slot(self._layout[1], self.device) for _ in range(self.depth)]
+
+    def _pack(self, slot: _Slot, batch: dict) -> Tuple[dict, int]:
+        """Copy the batch's tensors into the slot's staging buffer; -> (field -> (offset, shape, dtype), bytes used)."""
+        lay, _ = self._layout
+        have = dict(_tensor_items(batch))
+        meta, used = {}, 0
+        for key, dtype, tail, off, cap in lay:
+            v = have[key]
+            if v.dtype != dtype or tuple(v.shape[1:]) != tail or v.shape[0] > self._max_b:
+                raise ValueError(f"batch field {key} changed layout: {tuple(v.shape)} {v.dtype}")
+            n = v.numel() * v.element_size()
+            slot.host[off:off + n].view(dtype).view(v.shape).copy_(v)
+            meta[key] = (off, tuple(v.shape), dtype)
+            used = max(used, off + n)
+        return meta, used
+
+    def _views(self, slot: _Slot, meta: dict, batch: dict) -> dict:
+        out = {f: batch[f] for f in HOST_FIELDS if f in batch}
+        for (f, t), (off, shape, dtype) in meta.items():
+            n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+            view = slot.dev[off:off + n].view(dtype).view(shape)
+            if t is None:
+                out[f] = view
+            else:
+                out.setdefault(f, {})[t] = view
+        return out
+
+    # ------------------------------------------------------------------ iteration
+    def __iter__(self) -> Iterator[dict]:
+        it = iter(self.loader)
+        ready: "queue.Queue" = queue.Queue(maxsize=self.depth)
+        free: "queue.Queue" = queue.Queue()
+        stop = threading.Event()
+        err: List[BaseException] = []
+        handed_out = [False]
+
+        def work():
+            try:
+                for batch in it:
+                    if stop.is_set():
+                        return
+                    if self._layout is None:
+                        self._make_layout(batch)
+                    if not handed_out[0]:                 # once per epoch: every slot starts free
+                        handed_out[0] = True
+                        for s in self._slots:
+                            free.put(s)
+                    slot = free.get()
+                    if stop.is_set():
+                        return
+                    if self.cuda:
+                        slot.released.synchronize()       # the step that read this slot is done
+                    meta, used = self._pack(slot, batch)
+                    if self.cuda:
+                        with torch.cuda.stream(self.copy_stream):
+                            slot.dev[:used].copy_(slot.host[:used], non_blocking=True)
+                            slot.copied.record(self.copy_stream)
+                    self.h2d_bytes += used
+                    ready.put((slot, meta, batch))
+            except BaseException as e:      # surfaced in the consumer
+                err.append(e)
+            finally:
+                ready.put(None)
+
+        th = threading.Thread(target=work, name="fvqa-batch-producer", daemon=True)
+        th.start()
+        prev: Optional[_Slot] = None
+        try:
+            while True:
+                item = ready.get()
+                if prev is not None:                      # the consumer has issued the step that used `prev`
+                    if self.cuda:
+                        prev.released.record(torch.cuda.current_stream(self.device))
+                    free.put(prev)
+                    prev = None
+                if item is None:
+                    break
+                slot, meta, batch = item
+                if self.cuda:
+                    torch.cuda.current_stream(self.device).wait_event(slot.copied)
+                prev = slot
+                yield self._views(slot, meta, batch)
+        finally:
+            stop.set()
+            free.put(None)
+            while th.is_alive():
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+        if err:
+            raise err[0]

@@ -18,6 +18,7 @@ import torch
 import util.misc as misc
 from engine import train_one_epoch
 from fvqa import synth
+from fvqa.batch_producer import DeviceBatchProducer
 from fvqa.optim import FusedAdamW, param_groups_weight_decay
 from fvqa.parallel import DataParallel
 from llama_vqa import LLaMA_VQA
@@ -99,11 +100,7 @@ def build_loaders(args, model):
                                 max_feats=args.max_feats, max_seq_len=args.max_seq_len, batch_size=args.batch_size,
                                 vaq=args.vaq, qav=args.qav)
         return synth.SyntheticLoader(cfg, args.synthetic_batches, misc.get_rank(), misc.get_world_size(), pin=True), None
-    try:                                     # the reference's dataset readers, if they are on PYTHONPATH
-        from dataloader import load_data
-    except ImportError as e:
-        raise RuntimeError("dataset readers are host-side code outside this package; put the reference's "
-                           "`dataloader` on PYTHONPATH or use --synthetic") from e
+    from dataloader import load_data          # NExT-QA reader + collate of this package (dataloader/)
     return load_data(args, model.tokenizer, split="train"), load_data(args, model.tokenizer, split="val")
 
 
@@ -146,7 +143,9 @@ def main(args):
         sampler = getattr(train_loader, "sampler", None)
         if args.distributed and hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)
-        train_stats = train_one_epoch(model, train_loader, optimizer, epoch, loss_scaler, args=args)
+        # pinned single-copy H2D staging on a side stream: the step never waits for a pageable copy
+        staged = DeviceBatchProducer(train_loader, torch.device("cuda", args.gpu), depth=3)
+        train_stats = train_one_epoch(model, staged, optimizer, epoch, loss_scaler, args=args)
         log_stats = {**{f"train_{k}": v for k, v in train_stats.items()}, "epoch": epoch}
         val_stats = None
         if val_loader is not None:

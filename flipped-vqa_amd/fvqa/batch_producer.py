@@ -15,6 +15,7 @@ import queue
 import threading
 from typing import Dict, Iterable, Iterator, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 _ALIGN = 256
@@ -36,10 +37,42 @@ def _tensor_items(batch: dict) -> List[Tuple[Tuple[str, Optional[str]], torch.Te
     return items
 
 
+class PackedBatch:
+    """What a DataLoader worker hands over when packing is pushed into the workers: ONE uint8 tensor (one
+    shared-memory handle to receive instead of ~25) + the table of (field, task) -> (offset, shape, dtype) +
+    the host-side fields."""
+    __slots__ = ("blob", "meta", "host")
+
+    def __init__(self, blob, meta, host):
+        self.blob, self.meta, self.host = blob, meta, host
+
+
+class _PackingCollate:
+    """collate_fn wrapper: the reference-schema batch dict, flattened into a PackedBatch inside the worker."""
+
+    def __init__(self, collate_fn):
+        self.collate_fn = collate_fn
+
+    def __call__(self, samples):
+        batch = self.collate_fn(samples)
+        items = _tensor_items(batch)
+        meta, off = {}, 0
+        for key, v in items:
+            meta[key] = (off, tuple(v.shape), v.dtype)
+            off += (v.numel() * v.element_size() + _ALIGN - 1) // _ALIGN * _ALIGN
+        blob = np.empty(max(off, _ALIGN), dtype=np.uint8)
+        for key, v in items:
+            o = meta[key][0]
+            n = v.numel() * v.element_size()
+            blob[o:o + n] = v.contiguous().numpy().reshape(-1).view(np.uint8)
+        return PackedBatch(torch.from_numpy(blob), meta, {f: batch[f] for f in HOST_FIELDS if f in batch})
+
+
 class _Slot:
     def __init__(self, nbytes: int, device: torch.device):
         cuda = device.type == "cuda"
         self.host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=cuda)
+        self.host_np = self.host.numpy()                          # same (pinned) memory
         self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device) if cuda else self.host
         self.copied = torch.cuda.Event() if cuda else None       # H2D of this slot finished
         self.released = torch.cuda.Event() if cuda else None     # compute stream is past the consumer step
@@ -47,8 +80,14 @@ class _Slot:
 
 
 class DeviceBatchProducer:
-    def __init__(self, loader: Iterable[dict], device, depth: int = 2):
+    def __init__(self, loader: Iterable[dict], device, depth: int = 2, pack_in_workers: bool = True):
+        """pack_in_workers: when `loader` is a torch DataLoader with worker processes, wrap its collate_fn so
+        that the flattening into one buffer happens in the workers; the training process then spends ~0.2 ms
+        of interpreter time per batch (one tensor to receive, one memcpy, one H2D) instead of ~3 ms."""
         self.loader = loader
+        if pack_in_workers and getattr(loader, "num_workers", 0) > 0 and hasattr(loader, "collate_fn") \
+                and not isinstance(loader.collate_fn, _PackingCollate):
+            loader.collate_fn = _PackingCollate(loader.collate_fn)
         self.device = torch.device(device)
         self.depth = max(2, int(depth))
         self.cuda = self.device.type == "cuda"
@@ -83,7 +122,10 @@ class DeviceBatchProducer:
             if v.dtype != dtype or tuple(v.shape[1:]) != tail or v.shape[0] > self._max_b:
                 raise ValueError(f"batch field {key} changed layout: {tuple(v.shape)} {v.dtype}")
             n = v.numel() * v.element_size()
-            slot.host[off:off + n].view(dtype).view(v.shape).copy_(v)
+            # plain memcpy through numpy: a torch CPU op here would wake the whole intra-op thread pool
+            # (128 threads on the MI355X host) for a few KB — measured 24 ms per batch against 0.1 ms
+            src = v.contiguous().numpy().reshape(-1).view(np.uint8)
+            np.copyto(slot.host_np[off:off + n], src)
             meta[key] = (off, tuple(v.shape), dtype)
             used = max(used, off + n)
         return meta, used
@@ -113,8 +155,13 @@ class DeviceBatchProducer:
                 for batch in it:
                     if stop.is_set():
                         return
+                    packed = isinstance(batch, PackedBatch)
                     if self._layout is None:
-                        self._make_layout(batch)
+                        if packed:
+                            self._layout = ([], int(batch.blob.numel()))
+                            self._slots = [_Slot(self._layout[1], self.device) for _ in range(self.depth)]
+                        else:
+                            self._make_layout(batch)
                     if not handed_out[0]:                 # once per epoch: every slot starts free
                         handed_out[0] = True
                         for s in self._slots:
@@ -124,7 +171,14 @@ class DeviceBatchProducer:
                         return
                     if self.cuda:
                         slot.released.synchronize()       # the step that read this slot is done
-                    meta, used = self._pack(slot, batch)
+                    if packed:
+                        used = int(batch.blob.numel())
+                        if used > self._layout[1]:
+                            raise ValueError("a later batch is larger than the first one: staging slots too small")
+                        np.copyto(slot.host_np[:used], batch.blob.numpy())
+                        meta, batch = batch.meta, batch.host
+                    else:
+                        meta, used = self._pack(slot, batch)
                     if self.cuda:
                         with torch.cuda.stream(self.copy_stream):
                             slot.dev[:used].copy_(slot.host[:used], non_blocking=True)

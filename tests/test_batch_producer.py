@@ -158,6 +158,24 @@ def test_producer_passthrough_cpu(data_root):
     assert seen == len(src)
 
 
+def test_producer_packs_in_dataloader_workers(data_root):
+    """With a real DataLoader and worker processes the flattening happens in the workers (one tensor per batch
+    crosses the process boundary); what the consumer sees is unchanged."""
+    from fvqa.batch_producer import DeviceBatchProducer
+    ds = make_dataset(data_root, 128, "train", False)
+    mk = lambda workers: torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, num_workers=workers,
+                                                     collate_fn=dataloader.batch_collate)
+    ref = list(mk(0))
+    loader = mk(2)
+    prod = DeviceBatchProducer(loader, "cpu", depth=2)
+    assert type(loader.collate_fn).__name__ == "_PackingCollate"
+    n = 0
+    for got, want in zip(prod, ref):
+        _equal_batches(got, want)
+        n += 1
+    assert n == len(ref) == 3                               # 8 samples: 3 + 3 + 2
+
+
 def test_producer_surfaces_loader_errors():
     from fvqa.batch_producer import DeviceBatchProducer
 

@@ -202,6 +202,67 @@ int launch_128(const void* A, const void* B, void* C, const void* R, float* tail
   return FVQA_OK;
 }
 
+// ---- skinny GEMM for the decode shape (M <= 16 rows: one new token per sequence; generation path) -----------
+// HBM-bound on the weight stream, so the layout is chosen for bytes in flight, not for MFMA rate: one 512-thread
+// workgroup per strip of 16 output columns, its 8 waves split K eight ways (each keeps 8 k-steps = 16 KiB of
+// weight + activation fragments in flight from global memory, no LDS staging), the 8 partial 16x16 blocks meet
+// in LDS. The MFMA is fed the weight strip as its row operand, so a lane ends up with 4 consecutive columns of
+// one row (the same transposed-block trick as the 256x256 epilogue).
+template <typename TO, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_skinny(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                      TO* __restrict__ C, const bf16_t* __restrict__ R, int M, int N,
+                                                      int K, int lda, int ldb, int ldc) {
+  __shared__ float part[8][16][20];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kw = K / 8;                                    // this wave's K range (K % 256 == 0)
+  int bn = n0 + li; bn = bn < N ? bn : N - 1;
+  int am = li < M ? li : M - 1;
+  const bf16_t* bp = B + (size_t)bn * ldb + (size_t)w * kw + 8 * g;
+  const bf16_t* ap = A + (size_t)am * lda + (size_t)w * kw + 8 * g;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < kw; k0 += 256) {
+    uint4 bf[8], af[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 32 * u;
+      const bool in = k < kw;
+      bf[u] = in ? *reinterpret_cast<const uint4*>(bp + k) : make_uint4(0, 0, 0, 0);
+      af[u] = in ? *reinterpret_cast<const uint4*>(ap + k) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) Mma<bf16_t>::run(bf[u], af[u], acc);     // D[n = 4g+r][m = li]
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[w][li][4 * g + r] = acc[r];           // [wave][m][n]
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
+    if (m < M && n0 + n < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) v += part[ww][m][n];
+      if (EPI == FVQA_EPI_RESIDUAL) v += to_f32<bf16_t>(R[(size_t)m * ldc + n0 + n]);
+      C[(size_t)m * ldc + n0 + n] = from_f32<TO>(v);
+    }
+  }
+}
+
+template <typename TO>
+int launch_skinny(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
+                  int epi, hipStream_t st) {
+  dim3 grid((N + 15) / 16), block(512);
+  if (epi == FVQA_EPI_RESIDUAL)
+    hipLaunchKernelGGL((gemm_nt_skinny<TO, FVQA_EPI_RESIDUAL>), grid, block, 0, st, (const bf16_t*)A,
+                       (const bf16_t*)B, (TO*)C, (const bf16_t*)R, M, N, K, lda, ldb, ldc);
+  else
+    hipLaunchKernelGGL((gemm_nt_skinny<TO, FVQA_EPI_NONE>), grid, block, 0, st, (const bf16_t*)A, (const bf16_t*)B,
+                       (TO*)C, (const bf16_t*)R, M, N, K, lda, ldb, ldc);
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
 }  // namespace
 
 #define FVQA_GEMM256_DEFAULT_MODE 6
@@ -213,7 +274,7 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
 // else the 128x128 kernel); 1 = 128x128 register-staged; 2 = 128x128 LDS-DMA; 3 = 256x256 default
 // loop; 4 = 256x256 plain 64-byte-row ring loop;
 // 7 = 256x256 wide-row (128-byte) two-stage ring; 8 = wide-row asymmetric rings (A x2, B x3, role-split DMA); 9 = the same with waves 4-7 staggered by half a stage (the default loop, tile width chosen per problem);
-// 10 / 11 = the default loop with the tile forced 192 / 256 columns wide;
+// 10 / 11 = the default loop with the tile forced 192 / 256 columns wide; 12 = the skinny (M <= 16) decode kernel;
 // 16+s = 256x256 default loop with exactly s K-splits (tests / tuning).
 extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail, int M, int N,
                             int K, int lda, int ldb, int ldc, int m_split, int dtype, int out_dtype, int epilogue,
@@ -239,6 +300,13 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
     const int mode = variant == 4 ? 0 : variant == 7 ? 2 : variant == 8 ? 3 : variant == 9 ? 6 : variant == 10 ? 63 : variant == 11 ? 61 : FVQA_GEMM256_DEFAULT_MODE;
     return fvqa_gemm_nt_256_impl(A, B, C, R, tail, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, m_split, dtype,
                                  out_dtype, epilogue, variant >= 16 ? variant - 16 : 0, mode, st);
+  }
+  const bool skinny_ok = dtype == FVQA_BF16 && M <= 16 && (K % 256) == 0 && tail == nullptr &&
+                         (epilogue == FVQA_EPI_NONE || epilogue == FVQA_EPI_RESIDUAL);
+  if (variant == 12 && !skinny_ok) return FVQA_ESHAPE;
+  if (skinny_ok && (variant == 0 || variant == 12)) {       // decode shape: stream the weights once at HBM speed
+    return out_dtype == FVQA_F32 ? launch_skinny<float>(A, B, C, R, M, N, K, lda, ldb, ldc, epilogue, st)
+                                 : launch_skinny<bf16_t>(A, B, C, R, M, N, K, lda, ldb, ldc, epilogue, st);
   }
   const bool glds = variant != 1;
   if (dtype == FVQA_BF16) {

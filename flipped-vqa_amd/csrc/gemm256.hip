@@ -290,6 +290,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
     }
     int sa = 0, sbs = 0;                                  // ring slots of stage u: u % 2, u % 3
     const bool late = w >= 4;                             // wave-uniform
+    // (a static s_setprio 1 for either half of the waves measured -5 % / 0 %: the stagger already orders them)
     // k-step-1 fragments of output rows 0-63 (B + first four A rows): consumed at once by waves 0-3,
     // held across the next barrier by waves 4-7 (16 deferred MFMAs = 256 cycles of cover)
     u32x4 hl[4], hb[4];

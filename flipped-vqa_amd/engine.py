@@ -52,3 +52,35 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     log.synchronize_between_processes()
     print("Averaged stats:", log)
     return {k: m.global_avg for k, m in log.meters.items()}
+
+
+def val_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer, epoch: int,
+                  args=None):
+    """Validation with the reference's signature and return value (reference engine.py:59-145), generation
+    mode (`--is_generation_task`, the mode every run script of the reference uses): greedy answer generation,
+    nearest-choice matching, accuracy overall and per question type. The per-choice-loss mode calls a model
+    branch the reference no longer has (its `inference` returns the generation tuple), so it is rejected."""
+    if not getattr(args, "is_generation_task", False):
+        raise NotImplementedError("validation is built for --is_generation_task (reference engine.py:78-86)")
+    model.eval()
+    log = misc.MetricLogger(delimiter="  ")
+    log.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    for data in log.log_every(data_loader, max(1, len(data_loader) // 4), f"Epoch: [{epoch}]"):
+        answer = data["answer"]
+        bsz = answer.shape[0]
+        with torch.no_grad():
+            best, extracted = model(data, inference=True)
+        if getattr(args, "output_dir", None):
+            import os
+            os.makedirs(os.path.join(args.output_dir, "extracted_answers"), exist_ok=True)
+            misc.save_result(extracted, os.path.join(args.output_dir, "extracted_answers"),
+                             "extracted_answers_epoch%d" % epoch)
+        hit = answer.to(best.device) == best
+        misc.log_qtype(data, hit, log, args)
+        log.update(lr=optimizer.param_groups[0]["lr"])
+        log.update(n=bsz, acc=hit.sum().item() / bsz)
+        if getattr(args, "debug", False):
+            break
+    log.synchronize_between_processes()
+    print("Averaged stats:", log)
+    return {k: m.global_avg for k, m in log.meters.items()}

@@ -147,6 +147,7 @@ class StepEngine:
         self.cos = cos.to(self.device).contiguous()
         self.sin = sin.to(self.device).contiguous()
         self._arena: Dict[tuple, Arena] = {}
+        self._gen_arena: Dict[tuple, Arena] = {}     # arenas of the generation path (VQA stream only)
         self._vstart: Dict[tuple, torch.Tensor] = {}
         self.saved = None
         self.keep_logits = False

@@ -188,10 +188,20 @@ class Transformer(nn.Module):
         return self._flat
 
     # ---- reference forward signature --------------------------------------------------------
+    @torch.no_grad()
+    def inference(self, data):
+        """Greedy generation of the answer + nearest-choice matching (reference llama/model.py:367-546):
+        -> (most_similar_indices (B,), extracted_answers list of dicts). KV-cached, batched: fvqa/generate.py."""
+        from fvqa import generate
+        eng = self.ensure_engine()
+        ids = generate.greedy_decode(eng, data)
+        best, sims, extracted = generate.match_answers(self, data, ids)
+        self.last_generation = {"ids": ids, "similarities": sims}
+        return best, extracted
+
     def forward(self, data, inference=False):
         if inference:
-            raise NotImplementedError("generation/eval path (reference llama/model.py:367-546) is not part of "
-                                      "the MI355X training hot path")
+            return self.inference(data)
         eng = self.ensure_engine()
         flat = self._flat
         named = dict(self.named_parameters())

@@ -332,3 +332,45 @@ def all_reduce_mean(value: float) -> float:
     t = torch.tensor(value, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t)
     return (t / get_world_size()).item()
+
+
+# ---- validation bookkeeping (reference util/misc.py:343-600) -----------------------------------------
+NEXTQA_GROUPS = {"C": (1, 2), "T": (3, 4, 5), "D": (6, 7, 8)}       # causal / temporal / descriptive type ids
+
+
+def log_qtype(data, hit, metric_logger: MetricLogger, args):
+    """Per-question-type accuracy meters for NExT-QA: C (CH, CW), T (TN, TC, TP), D (DL, DC, DO), Total — each
+    updated with weight = number of questions of the group in this batch (reference util/misc.py:443-449,526-532).
+    Other datasets of the reference are not built."""
+    if getattr(args, "dataset", "nextqa") != "nextqa":
+        return
+    eps = 1e-10
+    qtype = torch.as_tensor(data["qtype"]).cpu()
+    hit = torch.as_tensor(hit).cpu().to(torch.float64)
+    for name, ids in NEXTQA_GROUPS.items():
+        sel = torch.zeros_like(qtype, dtype=torch.bool)
+        for i in ids:
+            sel |= qtype == i
+        n = float(sel.sum())
+        metric_logger.update(n=n + eps, **{name: float(hit[sel].sum()) / (n + eps)})
+    n = float(qtype.numel())
+    metric_logger.update(n=n + eps, Total=float(hit.sum()) / n if n else 0.0)
+
+
+def save_result(result, result_dir, filename):
+    """Each rank writes `<filename>_rank<r>.json`; rank 0 concatenates them into `<filename>.json`
+    (reference util/misc.py:570-600, JSON list form)."""
+    import json
+    mine = os.path.join(result_dir, "%s_rank%d.json" % (filename, get_rank()))
+    with open(mine, "w") as f:
+        json.dump(result, f, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+    if is_dist_avail_and_initialized():
+        dist.barrier()
+    if is_main_process():
+        merged = []
+        for r in range(get_world_size()):
+            with open(os.path.join(result_dir, "%s_rank%d.json" % (filename, r))) as f:
+                merged += json.load(f)
+        with open(os.path.join(result_dir, "%s.json" % filename), "w") as f:
+            json.dump(merged, f)
+    return os.path.join(result_dir, "%s.json" % filename)

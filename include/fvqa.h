@@ -57,7 +57,9 @@ const char* fvqa_arch(void); /* "gfx950"                                     */
  * tail[(m - m_split)*N + n] (ACCUMULATED, +=) instead of C (adapter-query gradient rows).
  * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows.
  * variant 0 picks the kernel: 256x256-tile 4-stage LDS-DMA ring (+ split-K through `workspace`
- * when the output has too few tiles for 256 CUs) or the 128x128-tile kernel for small problems. */
+ * when the output has too few tiles for 256 CUs), the 128x128-tile kernel for small problems, or — bf16,
+ * M <= 16, K % 256 == 0 — the weight-streaming kernel of the generation path (one new token per
+ * sequence; llama/model.py:439-447 run row-wise). Other variant codes force a kernel (tests, tuning). */
 int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail,
                  int M, int N, int K, int lda, int ldb, int ldc, int m_split,
                  int dtype, int out_dtype, int epilogue, int variant,

@@ -27,12 +27,15 @@ class FakeSentencePiece:
 
     def encode(self, s):
         out = []
-        for piece in _PIECE.findall(s):
+        for k, piece in enumerate(_PIECE.findall(s)):
+            if k == 0 and piece == "Question":       # LLaMA: a piece that opens the string carries the word-start
+                out.append(894)                      # marker, "▁Question" = 894 (reference llama/model.py:519)
+                continue
             if piece in MARKERS:
                 out.append(MARKERS[piece])
                 continue
             i = 1000 + zlib.crc32(piece.encode("utf-8")) % 28000
-            while i in MARKERS.values():
+            while i in MARKERS.values() or i == 894:
                 i += 1
             out.append(i)
         return out

@@ -1,0 +1,90 @@
+"""Validation / generation path: the KV-cached greedy decode + nearest-choice matcher against
+a fixture generated from the reference's own `Transformer.inference` (oracle/gen_golden_eval.py), and the host
+bookkeeping of `engine.val_one_epoch` / `util.misc.log_qtype` / `save_result`."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import engine
+from util import misc
+
+GOLD = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_tiny.npz")))
+
+
+def golden_batch():
+    B = GOLD["answer"].shape[0]
+    return {"video": torch.from_numpy(GOLD["video"]), "text_id": {"vqa": torch.from_numpy(GOLD["text_id_vqa"])},
+            "label": {"vqa": torch.from_numpy(GOLD["label_vqa"])},
+            "video_start": {"vqa": GOLD["vstart_vqa"].tolist()}, "prefix_index": {"vqa": GOLD["prefix_vqa"].tolist()},
+            "answer": torch.from_numpy(GOLD["answer"]), "qtype": torch.from_numpy(GOLD["qtype"]),
+            "vid": [f"v{i}" for i in range(B)]}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generation_matches_reference(dtype):
+    """fp32 build: the 31 greedy tokens per sample, the chosen option and the similarities equal the reference's
+    (argmax over fp32 logits that agree to ~1e-6). bf16 build: same code path, checked for shape / determinism and
+    that the prompt part is untouched (token-exactness against an fp32 reference is not defined for bf16)."""
+    from fvqa import synth
+    from tests.gpu_util import build_model
+    cfg = synth.preset("tiny", vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4)
+    model, _ = build_model(cfg, dtype)
+    model.eval()
+    batch = golden_batch()
+    best, extracted = model(batch, inference=True)
+    ids = model.last_generation["ids"].cpu().numpy()
+    assert ids.shape == GOLD["ids_after"].shape and len(extracted) == ids.shape[0]
+    prefix = GOLD["prefix_vqa"]
+    for b in range(ids.shape[0]):
+        assert np.array_equal(ids[b, :prefix[b]], GOLD["text_id_vqa"][b, 0, :prefix[b]])       # prompt untouched
+    if dtype == torch.float32:
+        assert np.array_equal(ids, GOLD["ids_after"])
+        assert np.array_equal(best.cpu().numpy(), GOLD["best"])
+        assert np.allclose(model.last_generation["similarities"].cpu().numpy(), GOLD["sims"], atol=2e-5)
+    else:
+        best2, _ = model(batch, inference=True)
+        assert torch.equal(best, best2) and np.array_equal(ids, model.last_generation["ids"].cpu().numpy())
+    # the training path still works on the same engine afterwards (separate arenas)
+    from fvqa import synth as S2
+    tb = S2.make_batch(cfg, seed=0)
+    loss = model(tb)[0]
+    assert torch.isfinite(loss)
+
+
+def test_log_qtype_matches_reference_formulas():
+    """C / T / D / Total meters as util/misc.py:443-449 of the reference computes them."""
+    log = misc.MetricLogger()
+    data = {"qtype": torch.tensor([1, 2, 3, 6, 6, 8])}
+    hit = torch.tensor([True, False, True, True, False, True])
+    misc.log_qtype(data, hit, log, types.SimpleNamespace(dataset="nextqa"))
+    eps = 1e-10
+    assert log.meters["C"].global_avg == pytest.approx((1 / (2 + eps)) * (2 + eps) / (2 + eps))
+    assert log.meters["T"].global_avg == pytest.approx(1 / (1 + eps))
+    assert log.meters["D"].global_avg == pytest.approx(2 / (3 + eps))
+    assert log.meters["Total"].global_avg == pytest.approx(4 / 6)
+    misc.log_qtype(data, hit, log, types.SimpleNamespace(dataset="star"))       # not built: no meters added
+    assert set(log.meters) == {"C", "T", "D", "Total"}
+
+
+def test_val_one_epoch_bookkeeping(tmp_path):
+    class Stub(torch.nn.Module):
+        def forward(self, data, inference=False):
+            assert inference
+            pred = data["answer"].clone()
+            pred[0] = (pred[0] + 1) % 5                      # one miss per batch
+            return pred, [{"video_id": v, "question": "", "generated_answer": ""} for v in data["vid"]]
+
+    batches = [{"answer": torch.tensor([0, 1, 2, 3]), "qtype": torch.tensor([1, 3, 6, 8]), "vid": list("abcd")}] * 3
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.5}])
+    args = types.SimpleNamespace(is_generation_task=True, dataset="nextqa", debug=False, output_dir=str(tmp_path))
+    stats = engine.val_one_epoch(Stub(), batches, opt, epoch=2, args=args)
+    assert stats["acc"] == pytest.approx(0.75) and stats["Total"] == pytest.approx(0.75) and stats["lr"] == 0.5
+    merged = json.load(open(tmp_path / "extracted_answers" / "extracted_answers_epoch2.json"))
+    assert [m["video_id"] for m in merged] == list("abcd")
+    with pytest.raises(NotImplementedError):
+        engine.val_one_epoch(Stub(), batches, opt, 0, args=types.SimpleNamespace(is_generation_task=False))

@@ -104,6 +104,27 @@ def test_gemm_nt_192_wide_tiles(dtype, M, N, K):
     assert rel(o32, ref) < tol(dtype, 5e-5, 2e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (1, 520, 256), (16, 1000, 2816), (3, 22016, 1024)])
+def test_gemm_nt_skinny_decode_shape(M, N, K):
+    """M <= 16 (one new token per sequence, generation path): the weight-streaming kernel, forced (variant 12)
+    and picked automatically (variant 0); bf16 and fp32 outputs, residual epilogue; ragged N."""
+    dtype = torch.bfloat16
+    a, b = rnd(M, K, dtype=dtype, seed=61), rnd(N, K, dtype=dtype, scale=1 / math.sqrt(K), seed=62)
+    r = rnd(M, N, dtype=dtype, seed=63)
+    ref = a.double() @ b.double().T
+    o12 = torch.empty(M, N, dtype=dtype, device=DEV)
+    o0 = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), o12, residual=dev(r), variant=12)
+    ops.gemm_nt(dev(a), dev(b), o0, residual=dev(r))
+    assert rel(o12, ref + r.double()) < 1e-2
+    assert torch.equal(o12, o0)
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), o32, variant=12)
+    assert rel(o32, ref) < 2e-3
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(dev(rnd(32, K, dtype=dtype)), dev(b), torch.empty(32, N, dtype=dtype, device=DEV), variant=12)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_nt_tail_round_plan(dtype):
     """More tiles than CUs with a partly filled last round: the last N-tile columns run as a second,

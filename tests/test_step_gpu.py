@@ -179,5 +179,5 @@ def test_forward_rejects_bad_inputs():
     bad["text_id"]["vqa"][0, 0, 3] = cfg.vocab_size + 5
     with pytest.raises(ValueError):
         model(bad)
-    with pytest.raises(NotImplementedError):
-        model(batch, inference=True)
+    with pytest.raises(ValueError):
+        model(batch, inference=True)          # a training batch has no prefix_index: generation refuses it

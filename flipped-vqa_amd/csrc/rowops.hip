@@ -56,10 +56,19 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, co
                                                      int splits, size_t plane, const T* __restrict__ resid,
                                                      const T* __restrict__ w, T* __restrict__ h,
                                                      T* __restrict__ y, float* __restrict__ rstd, int dim,
-                                                     float eps) {
+                                                     float eps, int rows, const float* __restrict__ cast_src) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)row * dim;
+  if (row >= rows) {        // rows riding under the normalised ones: y[row] = storage-dtype cast of fp32 cast_src
+    const float* src = cast_src + (size_t)(row - rows) * dim;      // (next layer's adapter rows, llama/model.py:339)
+    for (int c = tid * 8; c < dim; c += 2048) {
+      float v[8];
+      load8<float>(src + c, v);
+      store8<T>(y + base + c, v);
+    }
+    return;
+  }
   float xv[NORM_MAXK][8];
   float ss = 0.f;
 #pragma unroll
@@ -101,10 +110,23 @@ template <typename T, bool SUM>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ g, const float* __restrict__ ws,
                                                      int splits, size_t plane, const T* __restrict__ x,
                                                      const T* __restrict__ w, const float* __restrict__ rstd,
-                                                     const T* __restrict__ resid, T* __restrict__ dx, int dim) {
+                                                     const T* __restrict__ resid, T* __restrict__ dx, int dim,
+                                                     int rows, float* __restrict__ tail) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)row * dim;
+  if (row >= rows) {        // tail[r, :] += sum_s ws[s][rows + r, :] (fp32 adapter-gradient rows under the split-K GEMM)
+    float* t = tail + (size_t)(row - rows) * dim;
+    for (int c = tid * 8; c < dim; c += 2048) {
+      float v[8], u[8];
+      load8_sum(ws + base + c, splits, plane, v);
+      load8<float>(t + c, u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) u[i] += v[i];
+      store8<float>(t + c, u);
+    }
+    return;
+  }
   float xv[NORM_MAXK][8], gw[NORM_MAXK][8];
   float dot = 0.f;
 #pragma unroll
@@ -141,21 +163,6 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ g, co
       }
       store8<T>(dx + base + c, o);
     }
-  }
-}
-
-// tail[r, :] += sum_s ws[s][row0 + r, :]   (fp32 adapter-gradient rows riding under a split-K GEMM)
-__global__ __launch_bounds__(256) void sum_tail_k(const float* __restrict__ ws, int splits, size_t plane, int row0,
-                                                  float* __restrict__ tail, int dim) {
-  const size_t base = (size_t)(row0 + blockIdx.x) * dim;
-  float* t = tail + (size_t)blockIdx.x * dim;
-  for (int c = threadIdx.x * 8; c < dim; c += 2048) {
-    float v[8], u[8];
-    load8_sum(ws + base + c, splits, plane, v);
-    load8<float>(t + c, u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] += v[i];
-    store8<float>(t + c, u);
   }
 }
 
@@ -314,20 +321,20 @@ extern "C" int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rs
   if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T, false>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)x, nullptr, 0, 0, nullptr, (const T*)w, nullptr, (T*)y, rstd, dim,
-                                       eps));
+                                       eps, rows, nullptr));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
 
 extern "C" int fvqa_sumres_rmsnorm_fwd(const float* ws, int splits, size_t plane, const void* resid, const void* w,
-                                       void* h, void* y, float* rstd, int rows, int dim, float eps, int dtype,
-                                       void* stream) {
+                                       void* h, void* y, float* rstd, int rows, int dim, float eps,
+                                       const float* tail_src, int tail_rows, int dtype, void* stream) {
   if (!ws || !resid || !w || !h || !y) return FVQA_EINVAL;
-  if (!fvqa_dtype_ok(dtype) || splits < 1) return FVQA_EINVAL;
-  if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
-                                       nullptr, ws, splits, plane, (const T*)resid, (const T*)w, (T*)h, (T*)y, rstd,
-                                       dim, eps));
+  if (!fvqa_dtype_ok(dtype) || splits < 1 || (tail_rows > 0 && !tail_src)) return FVQA_EINVAL;
+  if (!norm_dims_ok(rows, dim) || tail_rows < 0) return FVQA_ESHAPE;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T, true>), dim3(rows + tail_rows), dim3(256), 0,
+                                       (hipStream_t)stream, nullptr, ws, splits, plane, (const T*)resid, (const T*)w,
+                                       (T*)h, (T*)y, rstd, dim, eps, rows, tail_src));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
@@ -339,7 +346,7 @@ extern "C" int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, con
   if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T, false>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)g, nullptr, 0, 0, (const T*)x, (const T*)w, rstd, (const T*)resid,
-                                       (T*)dx, dim));
+                                       (T*)dx, dim, rows, nullptr));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
@@ -350,12 +357,9 @@ extern "C" int fvqa_sum_rmsnorm_bwd(const float* ws, int splits, size_t plane, c
   if (!ws || !x || !w || !rstd || !dx) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype) || splits < 1 || (tail_rows > 0 && !tail)) return FVQA_EINVAL;
   if (!norm_dims_ok(rows, dim) || tail_rows < 0) return FVQA_ESHAPE;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
-                                       nullptr, ws, splits, plane, (const T*)x, (const T*)w, rstd, (const T*)resid,
-                                       (T*)dx, dim));
-  if (tail_rows > 0)
-    hipLaunchKernelGGL(sum_tail_k, dim3(tail_rows), dim3(256), 0, (hipStream_t)stream, ws, splits, plane, rows, tail,
-                       dim);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T, true>), dim3(rows + tail_rows), dim3(256), 0,
+                                       (hipStream_t)stream, nullptr, ws, splits, plane, (const T*)x, (const T*)w, rstd,
+                                       (const T*)resid, (T*)dx, dim, rows, tail));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }

@@ -85,7 +85,7 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
     float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
     float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
-    RUN(fvqa_cast_rows(p->adapter + (size_t)i * A * D, xn_tail, A, D, dt, stream));
+    if (i == 0) RUN(fvqa_cast_rows(p->adapter, xn_tail, A, D, dt, stream));   // later layers: in the norm kernel
     RUN(fvqa_gemm_nt(p->xn, p->wqkv[i], qkv, nullptr, nullptr, Ra, 3 * D, D, D, D, 3 * D, Ra, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
     if (fused_rope) {                                  // bf16 MFMA build: q,k stay raw and are rotated inside
@@ -101,7 +101,7 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     RUN(fvqa_gemm_nt(o, p->wo[i], nullptr, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_PARTIAL, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
     RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, x, p->fn[i], h, p->hn,
-                                p->rstd2 + (size_t)i * R, R, D, p->eps, dt, stream));
+                                p->rstd2 + (size_t)i * R, R, D, p->eps, nullptr, 0, dt, stream));
     RUN(fvqa_gemm_nt(p->hn, p->w13[i], ab, nullptr, nullptr, R, 2 * Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
     RUN(fvqa_swiglu_fwd(ab, p->z, R, Hf, dt, stream));
@@ -110,10 +110,11 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
                      p->gemm_ws, p->gemm_ws_bytes, stream));
     if (i + 1 < L) {
       RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->an[i + 1], x_next, p->xn,
-                                  p->rstd1 + (size_t)(i + 1) * R, R, D, p->eps, dt, stream));
+                                  p->rstd1 + (size_t)(i + 1) * R, R, D, p->eps, p->adapter + (size_t)(i + 1) * A * D, A,
+                                  dt, stream));
     } else {
       RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->norm_w, x_next, p->xnf, p->rstdN,
-                                  R, D, p->eps, dt, stream));
+                                  R, D, p->eps, nullptr, 0, dt, stream));
     }
   }
   return FVQA_OK;

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL, EPI_SWIGLU_BWD = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -27,7 +27,7 @@ SIGNATURES = {
     "fvqa_gemm_timing_read": (_i, [_i, _p, _p, _p]),
     "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
     "fvqa_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "fvqa_sumres_rmsnorm_fwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),
+    "fvqa_sumres_rmsnorm_fwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
     "fvqa_sum_rmsnorm_bwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fvqa_rope_qk": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_swiglu_fwd": (_i, [_p, _p, _i, _i, _i, _p]),

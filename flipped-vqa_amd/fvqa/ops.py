@@ -182,9 +182,15 @@ def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, da
 
 
 # ------------------------------------------------------------------------------------ row ops
-def sumres_rmsnorm_fwd(ws, resid, w, h, y, rstd, eps: float, rows: int):
-    """h = round(resid + sum_s ws[s]); y = RMSNorm(h) * w  (first `rows` rows)."""
-    _dev(ws, resid, w, h, y, rstd)
+def sumres_rmsnorm_fwd(ws, resid, w, h, y, rstd, eps: float, rows: int, tail_src=None):
+    """h = round(resid + sum_s ws[s]); y = RMSNorm(h) * w  (first `rows` rows); tail_src (n, dim) fp32: rows
+    [rows, rows+n) of y <- storage-dtype cast of tail_src (the next layer's adapter rows)."""
+    _dev(ws, resid, w, h, y, rstd, tail_src)
+    tail_rows = 0
+    if tail_src is not None:
+        tail_rows = tail_src.shape[0]
+        _need(tail_src.dtype == torch.float32 and tail_src.dim() == 2 and tail_src.shape[1] == ws.shape[2] and
+              tail_src.is_contiguous() and y.numel() >= (rows + tail_rows) * ws.shape[2], "sumres_rmsnorm_fwd: tail_src")
     splits, Mt, dim = ws.shape
     _need(ws.dtype == torch.float32 and rows <= Mt, "sumres_rmsnorm_fwd: ws")
     _need(resid.dtype == w.dtype == h.dtype == y.dtype and w.numel() == dim, "sumres_rmsnorm_fwd: dtype")
@@ -192,7 +198,8 @@ def sumres_rmsnorm_fwd(ws, resid, w, h, y, rstd, eps: float, rows: int):
         _need(t.shape[-1] == dim and t.numel() >= rows * dim, "sumres_rmsnorm_fwd: rows")
     _need(rstd.dtype == torch.float32 and rstd.numel() >= rows, "sumres_rmsnorm_fwd: rstd")
     rc = _lib.load().fvqa_sumres_rmsnorm_fwd(_ptr(ws), splits, Mt * dim, _ptr(resid), _ptr(w), _ptr(h), _ptr(y),
-                                             _ptr(rstd), rows, dim, float(eps), dt_code(h.dtype), _stream())
+                                             _ptr(rstd), rows, dim, float(eps), _ptr(tail_src), tail_rows,
+                                             dt_code(h.dtype), _stream())
     _lib.check(rc, "fvqa_sumres_rmsnorm_fwd")
 
 

@@ -294,9 +294,9 @@ class StepEngine:
         # following "residual add + RMSNorm" kernel sums them (no separate fix-up pass, no extra
         # round trip of the residual stream through HBM).
         ops.rmsnorm_fwd(ar.xs[0], pk.an[0], ar.xn, ar.rstd1[0], self.eps, rows=R)
+        ops.cast_rows(adapter[0], ar.xn[R:Ra])                    # later layers: cast rides in the norm kernel
         for i in range(L):
             x = ar.xs[i]
-            ops.cast_rows(adapter[i], ar.xn[R:Ra])
             ops.gemm_nt(ar.xn, pk.wqkv[i], ar.qkv[i])
             g1, g2 = m.gate_views(i)
             if ops.attn_rope_fused(self.dtype):             # bf16 MFMA build: q,k stay raw, rotated inside
@@ -311,7 +311,8 @@ class StepEngine:
             ops.swiglu_fwd(ar.ab[i], ar.z, R, Hf)
             ws, _ = ops.gemm_nt_partial(ar.z, pk.w2[i])
             if i + 1 < L:
-                ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.an[i + 1], ar.xs[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, R)
+                ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.an[i + 1], ar.xs[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, R,
+                                       tail_src=adapter[i + 1])
             else:
                 ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.norm, ar.xs[L], ar.xnf, ar.rstdN, self.eps, R)
 

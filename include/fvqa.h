@@ -85,10 +85,12 @@ int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, const float* r
                      const void* resid, void* dx, int rows, int dim, int dtype, void* stream);
 
 /* Fused consumers of FVQA_EPI_PARTIAL GEMMs (plane = M_total*dim elements between splits):
- * h = round(resid + sum_s ws[s]) (the residual stream, llama/model.py:185-186), y = RMSNorm(h)*w */
+ * h = round(resid + sum_s ws[s]) (the residual stream, llama/model.py:185-186), y = RMSNorm(h)*w;
+ * rows [rows, rows+tail_rows) of y receive the storage-dtype cast of the fp32 `tail_src` rows
+ * (the next layer's adapter prompt riding under the sequence rows, llama/model.py:339). */
 int fvqa_sumres_rmsnorm_fwd(const float* ws, int splits, size_t plane, const void* resid,
                             const void* w, void* h, void* y, float* rstd, int rows, int dim,
-                            float eps, int dtype, void* stream);
+                            float eps, const float* tail_src, int tail_rows, int dtype, void* stream);
 /* dx = resid + rmsnorm_bwd(sum_s ws[s]; x, w, rstd); rows [rows, rows+tail_rows) of the partials
  * are added into the fp32 `tail` (adapter-query gradient rows) */
 int fvqa_sum_rmsnorm_bwd(const float* ws, int splits, size_t plane, const void* x, const void* w,

@@ -218,6 +218,11 @@ def test_partial_gemm_with_fused_norm_consumers(dtype, M, N, K, tail):
     assert rel(h, href) < tol(dtype, 5e-5, 1e-2)
     yr, rr = ref_cpu.rmsnorm_fwd(h.double().cpu(), w.double(), 1e-6)      # norm of the STORED residual stream
     assert rel(y, yr) < tol(dtype) and rel(rstd, rr[:, 0]) < 1e-5
+    # the same call with fp32 rows riding under the normalised ones (the next layer's adapter prompt)
+    extra = rnd(3, N, seed=26).float()
+    y2 = torch.full((R + 3, N), 9.0, dtype=dtype, device=DEV)
+    ops.sumres_rmsnorm_fwd(ws, dev(res), dev(w), h, y2, rstd, 1e-6, R, tail_src=dev(extra))
+    assert torch.equal(y2[:R], y) and torch.equal(y2[R:].cpu(), extra.to(dtype))
     x = rnd(R, N, dtype=dtype, seed=25)
     xr, xrs = ref_cpu.rmsnorm_fwd(x.double(), w.double(), 1e-6)
     dx = torch.empty(R, N, dtype=dtype, device=DEV)

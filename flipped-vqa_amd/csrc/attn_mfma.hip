@@ -689,7 +689,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
 
 // ------------------------------------------------------------------------------- backward, S <= 128: one kernel
 // One workgroup per (sequence, head) keeps Q, K, V, dO of the whole sequence in LDS (4 x 34 KiB) and runs the
-// three passes back to back: (A) wave = 16 queries -> dQ, row deltas; (B) wave = 16 keys -> dK, dV; (C) waves 4-7
+// three passes back to back: (A) wave = 16 queries -> row deltas (barrier), dQ; (B) wave = 16 keys -> dK, dV; (C) waves 4-7
 // -> the adapter keys' dK, dV (one 32-query group each, summed through LDS into this sequence's fp32 partial).
 // The batch reduction of the adapter partials and of the gate sums is done by the LAST workgroup of each head to
 // arrive (integer arrival counter in the workspace, self-resetting; partials are summed in sequence order, so the
@@ -814,6 +814,13 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
       for (int d = 0; d < 8; ++d) dq[d] = mma(kf8[d], sf, dq[d]);
     }
     const float dt = dtot - da;
+    // the row deltas are all pass B needs from pass A: publish them now, so that every wave can run its share of
+    // pass A (w/2+1 key groups) and of pass B (4 - w/2 query groups) back to back — 5 groups each, no idle tail
+    if (g == 0) {
+      sDa[r16] = da;
+      sDt[r16] = dt;
+    }
+    __syncthreads();
     const int ng = min(gmax, (w >> 1) + 1);               // keys 0 .. 16w+15
     for (int gq = 0; gq < ng; ++gq) {
       uint4 kfr[2][4], vfr[2][4];
@@ -859,12 +866,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
         store4<ROPE>(row + 16 * d, x, cr + 8 * d, sr + 8 * d);
       }
     }
-    if (g == 0) {
-      sDa[r16] = da;
-      sDt[r16] = dt;
-    }
   }
-  __syncthreads();
 
   // ---- pass B: dK, dV of keys 16w..16w+15 (this lane: key r16; rows >= S are zero in LDS)
   f32x4 dk[8], dv[8];

@@ -66,6 +66,39 @@ def test_bf16_step_close_to_oracle(pname, over):
         assert err < 3e-2, (t, err)
 
 
+def test_bf16_full_7b_close_to_fp32_build():
+    """The production (bf16) build at FULL size — 32-layer 7B, BASELINE configs[0]: B=2, S=128, three losses —
+    against the fp32 build (itself pinned to the reference's golden for this very configuration) fed the same
+    bf16-rounded frozen weights. Same tolerances as the small bf16-vs-oracle cases."""
+    import gc
+    cfg = synth.preset("7b", batch_size=2, vaq=True, qav=True)
+    batch = synth.make_batch(cfg, seed=0)
+    model, _ = build_model(cfg, torch.float32)
+    for n, p in model.named_parameters():
+        if not synth.is_trainable(n):
+            p.data = p.data.to(torch.bfloat16).float()        # before the first forward packs the weights
+    l32, g32, _, _ = run_step(model, batch)
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+    model, _ = build_model(cfg, torch.bfloat16)
+    l16, g16, _, _ = run_step(model, batch)
+    for t in ("vqa", "vaq", "qav"):
+        assert abs(l16[t] - l32[t]) / abs(l32[t]) < BF16_LOSS_RTOL, (t, l16[t], l32[t])
+    worst = 0.0
+    for n, g in g32.items():
+        gn = float(g.norm())
+        if gn == 0:
+            continue
+        err = float((g16[n].double() - g.double()).norm()) / gn
+        worst = max(worst, err)
+        assert err < BF16_GRAD_RTOL, (n, err)
+    print("7B bf16 vs fp32 build: losses", l16, l32, "worst grad rel-L2", worst)
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def test_loss_weights_and_accumulation():
     """d(sum_k w_k loss_k): the backward honours per-loss upstream gradients, and two backward
     passes accumulate (gradient accumulation, engine.py:37-41)."""

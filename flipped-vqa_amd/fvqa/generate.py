@@ -10,7 +10,6 @@ The answer is then matched to the choices by cosine similarity of mean token emb
 reference's quirks kept (choices padded with id 0 before averaging, llama/model.py:566-575)."""
 from __future__ import annotations
 
-import os
 from typing import List, Tuple
 
 import torch
@@ -44,26 +43,21 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
         fused = ops.attn_rope_fused(eng.dtype)
         ids = ids_all[:, 0].to(dev).clone()
         prefix = torch.as_tensor([int(p) for p in data["prefix_index"]["vqa"]], device=dev)
-        ar_b = torch.arange(B, device=dev)
-        seq0 = ar_b * S
-        pos = (prefix - 1).clone()                          # start_idx of the first iteration
+        seq0 = torch.arange(B, device=dev) * S
+        pos = prefix - 1                                    # start_idx of the first iteration
         logits = ar.logits.view(B, S, V)
-        pred = logits[ar_b, pos.clamp(0, S - 1)].argmax(-1)
+        pred = logits[torch.arange(B, device=dev), pos.clamp(0, S - 1)].argmax(-1)
         e = lambda *s, dtype=eng.dtype: torch.empty(*s, dtype=dtype, device=dev)  # noqa: E731
-        xn, hn, h, xa, xb = e(B, D), e(B, D), e(B, D), e(B, D), e(B, D)
+        xn, hn, h, x2 = e(B, D), e(B, D), e(B, D), e(B, D)
         qkv_row, ab, z = e(B, 3 * D), e(B, 2 * Hf), e(B, Hf)
         lg = e(B, V, dtype=torch.float32)
-
-        def token_step():
-            """One generated token for every sample; all state (ids, pos, pred) lives on the device and is
-            updated in place, so the whole step can be replayed as a hipGraph."""
+        for _ in range(n_new):
             ok = pos + 1 < S                                # the reference would index past the end here
             tgt = (pos + 1).clamp(max=S - 1)
-            ids[ar_b, tgt] = torch.where(ok, pred, ids[ar_b, tgt])
-            pos.copy_(tgt)
+            ids[torch.arange(B, device=dev), tgt] = torch.where(ok, pred, ids[torch.arange(B, device=dev), tgt])
+            pos = tgt
             rows = seq0 + pos
-            xa.copy_(pk.emb[ids[ar_b, pos]])
-            x, x2 = xa, xb
+            x = pk.emb[ids[torch.arange(B, device=dev), pos]].contiguous()
             for i in range(L):
                 ops.rmsnorm_fwd(x, pk.an[i], xn, None, eng.eps, rows=B)
                 ops.gemm_nt(xn, pk.wqkv[i], qkv_row)
@@ -83,22 +77,7 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
                 x, x2 = x2, x
             ops.rmsnorm_fwd(x, pk.norm, xn, None, eng.eps, rows=B)
             ops.gemm_nt(xn, pk.wout, lg)
-            pred.copy_(lg.argmax(-1))
-
-        # The step is ~10 launches per layer of tiny kernels: launch-bound from Python. Run it once eagerly
-        # (warms every lazily created workspace / kernel attribute), then capture it as ONE hipGraph and replay.
-        use_graph = os.environ.get("FVQA_DECODE_GRAPH", "1") != "0" and n_new > 2
-        token_step()
-        if use_graph:
-            graph = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
-                token_step()
-            for _ in range(n_new - 2):
-                graph.replay()
-        else:
-            for _ in range(n_new - 1):
-                token_step()
+            pred = lg.argmax(-1)
         return ids
     finally:
         eng._gen_arena = eng._arena

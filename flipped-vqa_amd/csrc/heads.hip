@@ -42,6 +42,22 @@ __global__ __launch_bounds__(256) void visual_proj_fwd_k(const float* __restrict
   }
 }
 
+// vf_tok[r,d] = storage-dtype cast of vf_raw[r,d] + temporal[r % F, d]   (after the GEMM form of the projection)
+template <typename T>
+__global__ __launch_bounds__(256) void visual_tok_k(const float* __restrict__ vf_raw,
+                                                    const float* __restrict__ temporal, T* __restrict__ vf_tok,
+                                                    int R, int F, int D) {
+  const size_t n4 = (size_t)R * D / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i * 4 / D), d = (int)(i * 4 % D);
+    float v[4], t[4];
+    Vec4<float>::load(vf_raw + i * 4, v);
+    Vec4<float>::load(temporal + (size_t)(r % F) * D + d, t);
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    Vec4<T>::store(vf_tok + i * 4, v);
+  }
+}
+
 // dW[d,k] += sum_r (d_tok[r,d] + d_qav[r,d]) * video[r,k]
 template <int KMAX>
 __global__ __launch_bounds__(256) void visual_proj_bwd_k(const float* __restrict__ d_tok,
@@ -299,6 +315,24 @@ extern "C" int fvqa_visual_proj_fwd(const float* video, const float* W, const fl
     return FVQA_ESHAPE;
   dim3 grid((dim + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
+  // The wave-per-feature kernel re-reads the whole frame matrix for every output feature (1 GB of L2 traffic at
+  // D = 4096: 120 us). When the shapes fit the exact-fp32 MFMA GEMM (K % 32 == 0, 16-byte rows) the product runs
+  // there (same fp32 fma chains, ~10 us) and a small pass adds the temporal embedding and casts.
+  if (in_dim % 32 == 0 && dim % 4 == 0 && !(((uintptr_t)video | (uintptr_t)W | (uintptr_t)vf_raw) & 15)) {
+    int rc = fvqa_gemm_nt(video, W, vf_raw, nullptr, nullptr, n_frames_total, dim, in_dim, in_dim, in_dim, dim,
+                          n_frames_total, FVQA_F32, FVQA_F32, FVQA_EPI_NONE, 2, nullptr, 0, stream);
+    if (rc) return rc;
+    const size_t n4 = (size_t)n_frames_total * dim / 4;
+    const int g = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
+    if (dtype == FVQA_BF16)
+      hipLaunchKernelGGL(visual_tok_k<bf16_t>, dim3(g), block, 0, st, vf_raw, temporal, (bf16_t*)vf_tok,
+                         n_frames_total, max_feats, dim);
+    else
+      hipLaunchKernelGGL(visual_tok_k<float>, dim3(g), block, 0, st, vf_raw, temporal, (float*)vf_tok, n_frames_total,
+                         max_feats, dim);
+    FVQA_CHECK_LAUNCH();
+    return FVQA_OK;
+  }
   if (dtype == FVQA_BF16)
     hipLaunchKernelGGL((visual_proj_fwd_k<bf16_t, 32>), grid, block, 0, st, video, W, temporal, vf_raw,
                        (bf16_t*)vf_tok, n_frames_total, max_feats, in_dim, dim);

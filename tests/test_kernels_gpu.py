@@ -415,8 +415,9 @@ def test_attention_is_deterministic():
 
 # ------------------------------------------------------------------------------ heads, splice
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_visual_proj(dtype):
-    B, F, K, D = 3, 10, 768, 512
+@pytest.mark.parametrize("K", [768, 100])          # 768: product on the fp32 MFMA GEMM; 100: wave-per-feature kernel
+def test_visual_proj(dtype, K):
+    B, F, D = 3, 10, 512
     video, W, temp = rnd(B * F, K, seed=1), rnd(D, K, scale=1 / math.sqrt(K), seed=2), rnd(F, D, seed=3)
     raw = torch.empty(B * F, D, device=DEV)
     tok = torch.empty(B * F, D, dtype=dtype, device=DEV)

@@ -650,9 +650,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
           qa[t] = qb[t] = uint4{0u, 0u, 0u, 0u};
           if (m < M && nA < N) {
             if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
-              const T* rp = R + (size_t)m * 2 * N + nA;
+              const T* rp = R + (size_t)m * ldc + nA;        // ab rows: a | b halves, b at +ldc/2
               qa[t] = *reinterpret_cast<const uint4*>(rp);
-              qb[t] = *reinterpret_cast<const uint4*>(rp + N);
+              qb[t] = *reinterpret_cast<const uint4*>(rp + (ldc >> 1));
             } else {
               qa[t] = *reinterpret_cast<const uint4*>(R + (size_t)m * ldc + nA);
             }
@@ -686,7 +686,8 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
           if (nA < N) Vec4<float>::store(wp + nA, vA);
           if (nB < N) Vec4<float>::store(wp + nB, vB);
         } else if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
-          const size_t o = (size_t)m * 2 * N;
+          const size_t o = (size_t)m * ldc;
+          const int hb_ = ldc >> 1;
           float a_[8], b_[8], da[8], db[8];
           if constexpr (sizeof(T) == 2) {
             if (nA >= N) continue;
@@ -694,9 +695,9 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
             unpack8_bf16(qb[t], b_);
           } else {
             if (nA < N) { Vec4<T>::load(R + o + nA, reinterpret_cast<float(&)[4]>(a_[0]));
-                          Vec4<T>::load(R + o + N + nA, reinterpret_cast<float(&)[4]>(b_[0])); }
+                          Vec4<T>::load(R + o + hb_ + nA, reinterpret_cast<float(&)[4]>(b_[0])); }
             if (nB < N) { Vec4<T>::load(R + o + nB, reinterpret_cast<float(&)[4]>(a_[4]));
-                          Vec4<T>::load(R + o + N + nB, reinterpret_cast<float(&)[4]>(b_[4])); }
+                          Vec4<T>::load(R + o + hb_ + nB, reinterpret_cast<float(&)[4]>(b_[4])); }
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -706,12 +707,12 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
           }
           if constexpr (sizeof(TO) == 2) {
             store8<TO>(C + o + nA, da);
-            store8<TO>(C + o + N + nA, db);
+            store8<TO>(C + o + hb_ + nA, db);
           } else {
             if (nA < N) { Vec4<TO>::store(C + o + nA, reinterpret_cast<float(&)[4]>(da[0]));
-                          Vec4<TO>::store(C + o + N + nA, reinterpret_cast<float(&)[4]>(db[0])); }
+                          Vec4<TO>::store(C + o + hb_ + nA, reinterpret_cast<float(&)[4]>(db[0])); }
             if (nB < N) { Vec4<TO>::store(C + o + nB, reinterpret_cast<float(&)[4]>(da[4]));
-                          Vec4<TO>::store(C + o + N + nB, reinterpret_cast<float(&)[4]>(db[4])); }
+                          Vec4<TO>::store(C + o + hb_ + nB, reinterpret_cast<float(&)[4]>(db[4])); }
           }
         } else {
           TO* cp = C + (size_t)m * ldc;
@@ -761,10 +762,10 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
           Vec4<float>::store(tp, u);
         } else if (EPI == FVQA_EPI_SWIGLU_BWD) {
           // v = dz[m][n..n+3]; R = ab (rows of 2N: a | b); C = dab (rows of 2N): d(silu(a)*b)
-          const size_t o = (size_t)m * 2 * N + n;
+          const size_t o = (size_t)m * ldc + n;
           float a_[4], b_[4], da[4], db[4];
           Vec4<T>::load(R + o, a_);
-          Vec4<T>::load(R + o + N, b_);
+          Vec4<T>::load(R + o + (ldc >> 1), b_);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float sg = 1.f / (1.f + __expf(-a_[e]));
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
             db[e] = v[e] * a_[e] * sg;
           }
           Vec4<TO>::store(C + o, da);
-          Vec4<TO>::store(C + o + N, db);
+          Vec4<TO>::store(C + o + (ldc >> 1), db);
         } else {
           if (EPI == FVQA_EPI_RESIDUAL) {
             float r[4];
@@ -790,11 +791,11 @@ __global__ __launch_bounds__(512) void gemm_nt_256(const T* __restrict__ A, cons
           } else if (tail != nullptr && m >= m_split) {
             tail[(size_t)(m - m_split) * N + n + e] += v[e];
           } else if (EPI == FVQA_EPI_SWIGLU_BWD) {
-            const size_t o = (size_t)m * 2 * N + n + e;
-            const float a_ = to_f32<T>(R[o]), b_ = to_f32<T>(R[o + N]);
+            const size_t o = (size_t)m * ldc + n + e;
+            const float a_ = to_f32<T>(R[o]), b_ = to_f32<T>(R[o + (ldc >> 1)]);
             const float sg = 1.f / (1.f + __expf(-a_));
             C[o] = from_f32<TO>(v[e] * b_ * sg * (1.f + a_ * (1.f - sg)));
-            C[o + N] = from_f32<TO>(v[e] * a_ * sg);
+            C[o + (ldc >> 1)] = from_f32<TO>(v[e] * a_ * sg);
           } else {
             float x = v[e];
             if (EPI == FVQA_EPI_RESIDUAL) x += to_f32<T>(R[(size_t)m * ldc + n + e]);
@@ -830,6 +831,21 @@ __global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ ws
       u[0] += v[0]; u[1] += v[1]; u[2] += v[2]; u[3] += v[3];
       Vec4<float>::store(tp, u);
     } else {
+      if (EPI == FVQA_EPI_SWIGLU_BWD) {           // v = dz; R = ab rows (a | b at +ldc/2); C = dab
+        const size_t o = (size_t)m * ldc + n;
+        float a_[4], b_[4], da[4], db[4];
+        Vec4<T>::load(R + o, a_);
+        Vec4<T>::load(R + o + (ldc >> 1), b_);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sg = 1.f / (1.f + __expf(-a_[e]));
+          da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
+          db[e] = v[e] * a_[e] * sg;
+        }
+        Vec4<TO>::store(C + o, da);
+        Vec4<TO>::store(C + o + (ldc >> 1), db);
+        continue;
+      }
       if (EPI == FVQA_EPI_RESIDUAL) {
         float r[4];
         Vec4<T>::load(R + (size_t)m * ldc + n, r);
@@ -936,26 +952,31 @@ extern "C" int fvqa_gemm_splits(int M, int N, int K, int dtype) {
   return s;
 }
 
-// Tail-round plan for outputs with MORE tiles than CUs: the tiles of the last, partially filled
-// round (whole N-tile columns) are computed by a second launch that splits K, so the launch pair
-// takes 1 + 1/sr rounds instead of 2 (e.g. W1|W3: 344 tiles -> 256 + 88 x 2 halves).
-struct TailPlan { int n1; int sr; };
+// Tail-round plan for outputs with MORE tiles than CUs: the whole N-tile columns that do not fit into the full
+// rounds are computed by a second launch that splits K, so the launch pair takes `full + 1/sr` rounds instead of
+// `full + 1` (M = 1024, W1|W3: 344 tiles -> 256 + 88 x 2 halves; three streams, M = 3072, W1|W3: 1032 tiles ->
+// 1020 in 4 rounds + 12 x 8 eighths instead of 5 rounds).
+struct TailPlan { int n1; int sr; int rounds1; };
 static TailPlan tail_plan(int M, int N, int K, int dtype) {
-  TailPlan p = {N, 1};
+  TailPlan p = {N, 1, 0};
   const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
   const int tiles = tm * tn;
-  if (tiles <= 256 || (256 % tm) != 0 || (N % TN) != 0) return p;
-  const int cols_per_round = 256 / tm;
-  const int rounds = tn / cols_per_round;
-  const int rem_cols = tn - rounds * cols_per_round;
-  if (rounds < 1 || rem_cols == 0) return p;
-  int sr = 256 / (rem_cols * tm);
-  if (sr > 4) sr = 4;
+  if (tiles <= 256 || (N % TN) != 0) return p;
+  const int full = tiles / 256;
+  if (tiles % 256 == 0) return p;
+  const int c1 = full * 256 / tm;                       // N-tile columns that fit the full rounds
+  const int c2 = tn - c1;
+  if (c1 < 1 || c2 < 1) return p;
+  int sr = 256 / (c2 * tm);
+  if (sr > 8) sr = 8;
   const int nk = K / (dtype == FVQA_BF16 ? 32 : 16);
-  while (sr > 1 && nk / sr < 16) --sr;
+  while (sr > 1 && nk / sr < 16) --sr;                  // keep >= 16 stages per split: the ring needs a run-up
   if (sr < 2) return p;
-  p.n1 = rounds * cols_per_round * TN;
+  const int rounds1 = (tm * c1 + 255) / 256;
+  if (rounds1 + 1.0 / sr + 0.1 > (tiles + 255) / 256 - 0.15) return p;     // must beat the plain launch
+  p.n1 = c1 * TN;
   p.sr = sr;
+  p.rounds1 = rounds1;
   return p;
 }
 
@@ -975,7 +996,7 @@ static int pick_nt(int M, int N, int K, int dtype, bool tail_plan_ok) {
   double c256 = (double)((t256 + 255) / 256);
   if (tail_plan_ok) {
     const TailPlan p = tail_plan(M, N, K, dtype);
-    if (p.sr > 1) c256 = (double)(p.n1 / TN * tm / 256) + 1.0 / p.sr + 0.1;
+    if (p.sr > 1) c256 = (double)p.rounds1 + 1.0 / p.sr + 0.1;
   }
   // measured (profiles/r01_gemm_ablation_tilewidth.log): at equal rounds the narrower tile buys nothing —
   // the loop is bound by LDS/DMA traffic per stage, which shrinks 9 %, not by MFMA work, which shrinks 25 %
@@ -990,17 +1011,33 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
   int force_nt = 0;
   if (mode == 61) { force_nt = 4; mode = 6; }
   if (mode == 63) { force_nt = 3; mode = 6; }
-  if (epilogue == FVQA_EPI_SWIGLU_BWD) {       // elementwise epilogue on whole outputs: no K split
+  if (epilogue == FVQA_EPI_SWIGLU_BWD) {       // elementwise epilogue on whole outputs
+    const size_t ei = fvqa_dtype_size(dtype);
+    if (force_splits == 0 && force_nt == 0 && ws != nullptr) {
+      // tail-round plan: the columns past the full rounds run K-split and their fix-up pass applies SwiGLU'
+      const TailPlan p = tail_plan(M, N, K, dtype);
+      if (p.sr > 1 && ws_bytes >= (size_t)p.sr * M * (N - p.n1) * sizeof(float)) {
+        int rc = fvqa_gemm_nt_256_impl(A, B, C, R, nullptr, ws, ws_bytes, M, p.n1, K, lda, ldb, ldc, m_split, dtype,
+                                       out_dtype, epilogue, 1, 61, st);
+        if (rc) return rc;
+        return fvqa_gemm_nt_256_impl(A, (const char*)B + (size_t)p.n1 * ldb * ei, (char*)C + (size_t)p.n1 * ei,
+                                     (const char*)R + (size_t)p.n1 * ei, nullptr, ws, ws_bytes, M, N - p.n1, K, lda,
+                                     ldb, ldc, m_split, dtype, out_dtype, epilogue, p.sr, 61, st);
+      }
+    }
     const int nt = force_nt ? force_nt : pick_nt(M, N, K, dtype, false);
+    const int sp = force_splits > 1 ? force_splits : 1;
     if (dtype == FVQA_BF16)
-      return nt == 3 ? launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6, 3>(A, B, C, R, nullptr, (float*)ws, M, N, K,
-                                                                            lda, ldb, ldc, m_split, 1, false, st)
-                     : launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K,
-                                                                         lda, ldb, ldc, m_split, 1, false, st);
-    return nt == 3 ? launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6, 3>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda,
+      return nt == 3 && sp == 1
+                 ? launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6, 3>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda,
                                                                         ldb, ldc, m_split, 1, false, st)
-                   : launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda,
-                                                                     ldb, ldc, m_split, 1, false, st);
+                 : launch_256<bf16_t, bf16_t, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda, ldb,
+                                                                     ldc, m_split, sp, false, st);
+    return nt == 3 && sp == 1
+               ? launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6, 3>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda, ldb,
+                                                                    ldc, m_split, 1, false, st)
+               : launch_256<float, float, FVQA_EPI_SWIGLU_BWD, 6>(A, B, C, R, nullptr, (float*)ws, M, N, K, lda, ldb, ldc,
+                                                                 m_split, sp, false, st);
   }
   int splits = force_splits > 0 ? force_splits : fvqa_gemm_splits(M, N, K, dtype);
   const bool partial = epilogue == FVQA_EPI_PARTIAL;

@@ -168,12 +168,15 @@ def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, da
     _need(ab.numel() >= M * 2 * N and dab.numel() >= M * 2 * N and ab.shape[-1] == 2 * N and dab.shape[-1] == 2 * N,
           "gemm_nt_swiglu_bwd: ab/dab shape")
     lib = _lib.load()
+    need = int(lib.fvqa_gemm_workspace(M, N, K, dt_code(g.dtype)))      # tail-round plan of multi-stream shapes
+    ws = gemm_workspace(g.device, need) if need else None
     timing = GEMM_TIMING
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = lib.fvqa_gemm_nt(_ptr(g), _ptr(w2_t), _ptr(dab), _ptr(ab), None, M, N, K, K, K, 2 * N, M, dt_code(g.dtype),
-                          dt_code(g.dtype), EPI_SWIGLU_BWD, 0, None, 0, _stream())
+                          dt_code(g.dtype), EPI_SWIGLU_BWD, 0, _ptr(ws), ws.numel() if ws is not None else 0,
+                          _stream())
     if timing is not None:
         e1.record()
         timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[g.dtype]}_{_DTN[g.dtype]}_swiglu_plain"))

@@ -72,8 +72,10 @@ def test_gemm_nt_256_ring_and_splitk(dtype, variant, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,Hf,D", [(74, 768, 256), (1024, 1536, 512)])
+@pytest.mark.parametrize("M,Hf,D", [(74, 768, 256), (1024, 1536, 512), (3072, 11008, 1024)])   # last: tail-round plan
 def test_gemm_nt_swiglu_bwd_epilogue(dtype, M, Hf, D):
+    if dtype == torch.float32 and M > 1024:
+        pytest.skip("fp32 covered by the small shapes")
     g, w2t = rnd(M, D, dtype=dtype, seed=41), rnd(Hf, D, dtype=dtype, scale=1 / math.sqrt(D), seed=42)
     ab = rnd(M, 2 * Hf, dtype=dtype, scale=3, seed=43)
     dab = torch.empty(M, 2 * Hf, dtype=dtype, device=DEV)
@@ -126,17 +128,19 @@ def test_gemm_nt_skinny_decode_shape(M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_gemm_nt_tail_round_plan(dtype):
+@pytest.mark.parametrize("M,N,K", [(1024, 16896, 1024), (3072, 22016, 1024), (3082, 12288, 2048)])
+def test_gemm_nt_tail_round_plan(dtype, M, N, K):
     """More tiles than CUs with a partly filled last round: the last N-tile columns run as a second,
-    K-split launch (W1|W3-shaped problem, reduced K)."""
-    M, N, K = 1024, 16896, 1024
+    K-split launch (W1|W3 / QKV shaped problems of one and of three streams, reduced K)."""
+    if dtype == torch.float32 and M > 1024:
+        pytest.skip("fp32 covered by the single-stream shape")
     a, b = rnd(M, K, dtype=dtype, seed=31), rnd(N, K, dtype=dtype, scale=1 / math.sqrt(K), seed=32)
     r = rnd(M, N, dtype=dtype, seed=33)
     out = torch.empty(M, N, dtype=dtype, device=DEV)
     ops.gemm_nt(dev(a), dev(b), out, residual=dev(r))
     ref = a.double() @ b.double().T + r.double()
     assert rel(out, ref) < tol(dtype, 5e-5, 1e-2)
-    assert rel(out[:, -512:], ref[:, -512:]) < tol(dtype, 5e-5, 1e-2)       # the split columns
+    assert rel(out[:, -256:], ref[:, -256:]) < tol(dtype, 5e-5, 1e-2)       # the split columns
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -232,13 +232,13 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
   const bool biased_row = vs >= 0 && iq >= vs + F;
 
   for (int kt = 0; kt <= qb; ++kt) {
-    if (kt > 0) {
-      __syncthreads();                                    // tile kt-1 fully consumed
-      tile_load<BQ>(rK, seq + D, ld, kt * BQ, S);
-      tile_load<BQ>(rV, seq + 2 * D, ld, kt * BQ, S);
-    }
+    if (kt > 0) __syncthreads();                          // tile kt-1 fully consumed
     tile_commit<ROPE, BQ>(rK, sK, kt * BQ, S, cs, sn);
     tile_commit<false, BQ>(rV, sV, kt * BQ, S, nullptr, nullptr);
+    if (kt < qb) {                                        // next tile's loads fly under this tile's arithmetic
+      tile_load<BQ>(rK, seq + D, ld, (kt + 1) * BQ, S);
+      tile_load<BQ>(rV, seq + 2 * D, ld, (kt + 1) * BQ, S);
+    }
     __syncthreads();
     const int jlast = min(i0 + 15, S - 1) - kt * BQ;      // last tile-local key any row of this wave sees
     const int ng = jlast < 0 ? 0 : min(4, (jlast >> 5) + 1);
@@ -437,13 +437,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   }
   const float dt = dtot - da;
 
+  if (qb > 0) {                                           // tile 1's loads fly under tile 0's arithmetic
+    tile_load<BQ>(rK, seq + D, ld, BQ, S);
+    tile_load<BQ>(rV, seq + 2 * D, ld, BQ, S);
+  }
   for (int kt = 0; kt <= qb; ++kt) {
     if (kt > 0) {
       __syncthreads();                                    // tile kt-1 fully consumed
-      tile_load<BQ>(rK, seq + D, ld, kt * BQ, S);
-      tile_load<BQ>(rV, seq + 2 * D, ld, kt * BQ, S);
       tile_commit<ROPE, BQ>(rK, sK, kt * BQ, S, cs, sn);
       tile_commit<false, BQ>(rV, sV, kt * BQ, S, nullptr, nullptr);
+      if (kt < qb) {
+        tile_load<BQ>(rK, seq + D, ld, (kt + 1) * BQ, S);
+        tile_load<BQ>(rV, seq + 2 * D, ld, (kt + 1) * BQ, S);
+      }
       __syncthreads();
     }
     const int jlast = min(i0 + 15, S - 1) - kt * BQ;
@@ -573,21 +579,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   const float g2 = gate2[h];
   const bool win_key = vs >= 0 && jk >= vs && jk < vs + F;
   for (int t = t_first; t < nqt; ++t) {
-    if (t > t_first) {
-      __syncthreads();                                    // tile t-1 fully consumed
-      tile_load<BQ>(rQ, seq, ld, t * BQ, S);
-      tile_load<BQ>(rdO, dob, (size_t)D, t * BQ, S);
-      if (threadIdx.x < BQ) {
-        const int ii = min(t * BQ + (int)threadIdx.x, S - 1);
-        l_in = adapter ? lse_a[sbase + ii] : lse_t[sbase + ii];
-        d_in = adapter ? delta_a[sbase + ii] : delta_t[sbase + ii];
-      }
-    }
+    if (t > t_first) __syncthreads();                     // tile t-1 fully consumed
     tile_commit<ROPE, BQ>(rQ, sQ, t * BQ, S, cs, sn);
     tile_commit<false, BQ>(rdO, sdO, t * BQ, S, nullptr, nullptr);
     if (threadIdx.x < BQ) {
       sL[threadIdx.x] = l_in;
       sDl[threadIdx.x] = d_in;
+    }
+    if (t + 1 < nqt) {                                    // next tile's loads fly under this tile's arithmetic
+      tile_load<BQ>(rQ, seq, ld, (t + 1) * BQ, S);
+      tile_load<BQ>(rdO, dob, (size_t)D, (t + 1) * BQ, S);
+      if (threadIdx.x < BQ) {
+        const int ii = min((t + 1) * BQ + (int)threadIdx.x, S - 1);
+        l_in = adapter ? lse_a[sbase + ii] : lse_t[sbase + ii];
+        d_in = adapter ? delta_a[sbase + ii] : delta_t[sbase + ii];
+      }
     }
     __syncthreads();
     // 32-query groups of this tile that this wave works on

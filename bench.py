@@ -193,6 +193,15 @@ def main():
     if rank == 0:
         rec = ops.gemm_timing_read()
         ops.gemm_timing_enable(False)
+        # calibration: what an event pair with NOTHING between reads on this stream (the record-to-record spacing that
+        # every bracketed launch also contains); subtracted per launch so that the figure is the kernel's own duration
+        # (it then agrees with the rocprofv3 kernel-trace average of the same command, profiles/README.md)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(129)]
+        for ev in evs:
+            ev.record()
+        torch.cuda.synchronize()
+        gaps = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(128))
+        probe_overhead_us = gaps[len(gaps) // 2]
         epi_name = {0: "none", 1: "residual", 2: "partial", 3: "swiglu_bwd"}
         per = {}
         for (us, fl, kind) in rec:
@@ -201,7 +210,7 @@ def main():
             key = ("f32" if kind & 64 else "bf16") + "_" + ("f32" if kind & 32 else "bf16") + "_" + \
                 epi_name[kind & 15] + ("_splitk" if kind & 16 else "")
             t_, f_, n_ = per.get(key, (0.0, 0.0, 0))
-            per[key] = (t_ + us * 1e-6, f_ + fl, n_ + 1)
+            per[key] = (t_ + max(us - probe_overhead_us, 0.0) * 1e-6, f_ + fl, n_ + 1)
         if per:
             tot_t = sum(v[0] for v in per.values())
             tot_f = sum(v[1] for v in per.values())
@@ -219,6 +228,7 @@ def main():
                     "achieved": tot_f / tot_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": tot_f / tot_t / peak, "traffic": traffic, "traffic_source": tsrc,
                     "launches_per_step": n // a.steps, "avg_launch_us": tot_t / n * 1e6,
+                    "probe_overhead_us_subtracted": probe_overhead_us,
                     "avg_flops_per_launch": tot_f / n,
                     "per_instantiation": {k: {"launches_per_step": v[2] // a.steps, "avg_launch_us": v[0] / v[2] * 1e6,
                                               "TFLOP/s": v[1] / v[0] / 1e12} for k, v in per.items()}}

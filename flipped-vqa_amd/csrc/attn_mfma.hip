@@ -1008,10 +1008,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
   //  * the partials are WRITTEN with device-scope relaxed atomic stores (sc1: written through to memory);
   //    every thread waits for its own stores (workgroup-scope release = s_waitcnt vmcnt(0)), the barrier
   //    collects the workgroup, and only then one thread bumps the arrival counter (device-scope RMW);
-  //  * the adapter partials are READ with ordinary (pipelined) loads: each 128-byte line of them is written
-  //    whole by ONE workgroup and read by nobody before this point of the launch, so the reader's L1/L2 hold
-  //    no older copy (a copy in its L2 can only come from a same-XCD writer and is current); device-scope
-  //    loads of lines just written through measured 40 us slower;
+  //  * the last arriver does ONE device-scope acquire fence (lane 0, then a barrier) and reads the adapter
+  //    partials with ordinary (pipelined) loads — the recipe of cdna_hip_programming.md "Projection GEMM at
+  //    M = 256" item 2 for write-through slabs; device-scope (sc1) loads of every slab element instead
+  //    measured 40 us slower;
   //  * the gate partials share lines between heads, so they are read with device-scope (sc1) loads.
   for (int idx = threadIdx.x; idx < A * DH; idx += 512) {
     const int aa = idx / DH, d = idx % DH;
@@ -1031,11 +1031,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     __hip_atomic_store(gate_part + ((size_t)n * H + h) * 2, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(gate_part + ((size_t)n * H + h) * 2 + 1, b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave: its write-through stores have completed
   __syncthreads();
   if (threadIdx.x == 0) {
     const int old = __hip_atomic_fetch_add(arrive + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_flag = (old == n_seq - 1) ? 1 : 0;
+    if (last_flag) {                                      // the reducer: ONE device-scope acquire on behalf of the
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // workgroup before its ordinary loads of the other slabs
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
   if (!last_flag) return;

@@ -179,3 +179,19 @@ def test_train_cli_has_reference_flags():
     a.audio_only = True
     with pytest.raises(AssertionError):
         train.validate_args(a)
+
+
+def test_gemm_decomposition_plans_are_pinned():
+    """Host-only entries of the C ABI (no HIP call behind them): the split-K / tail-round plans the step relies on,
+    pinned through the workspace they ask for ([splits][M][N or tail columns] fp32)."""
+    lib = _lib.load()
+    BF16 = 1
+    ws = lambda M, N, K: int(lib.fvqa_gemm_workspace(M, N, K, BF16))
+    sp = lambda M, N, K: int(lib.fvqa_gemm_splits(M, N, K, BF16))
+    assert sp(1024, 4096, 4096) == 4 and ws(1024, 4096, 4096) == 4 * 1024 * 4096 * 4          # WO: 64 tiles x 4
+    assert sp(1034, 4096, 12288) == 3                                                         # QKV^T: 80 tiles x 3
+    assert sp(1024, 22016, 4096) == 1 and ws(1024, 22016, 4096) == 2 * 1024 * 5632 * 4        # W1|W3: 256 + 88 x 2
+    assert sp(1024, 12288, 4096) == 1 and ws(1034, 12288, 4096) == 0                          # QKV: one round, no plan
+    assert ws(1024, 32000, 4096) == 0                                                         # LM head: 500 tiles, tail too big
+    assert ws(3072, 22016, 4096) == 8 * 3072 * 256 * 4                                        # three streams: 1020 + 12 x 8
+    assert ws(3072, 11008, 4096) == 8 * 3072 * 256 * 4                                        # W2^T under SwiGLU': 504 + 12 x 8

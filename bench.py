@@ -81,6 +81,42 @@ def cpu_baseline_leg(seq_len, max_feats):
                       f"({times[1]:.2f}s, {times[2]:.2f}s) and scaled to 32 layers + head ({full:.1f}s/step)"}
 
 
+def launcher_command(n_gpus, argv, port=None, python=None):
+    """argv of the child that runs `bench.py <argv>` as n_gpus ranks of ONE node (one process per GPU,
+    RCCL over xGMI): the form the driver itself uses for N>1."""
+    if port is None:
+        import socket
+        with socket.socket() as s:               # a free port on the loopback interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launcher_env(n_gpus, n_devices, env=None):
+    """Environment of the child ranks. With fewer devices than ranks (a rehearsal of the N>1 control flow on a
+    smaller box) the ranks share devices and use gloo; the JSON line then carries "rehearsal": true."""
+    env = dict(os.environ if env is None else env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    if 0 < n_devices < n_gpus:
+        env.setdefault("FVQA_DIST_BACKEND", "gloo")
+        env["FVQA_BENCH_REHEARSAL"] = "1"
+    return env
+
+
+def self_launch(n_gpus, argv):
+    import subprocess
+    n_dev = torch.cuda.device_count()            # counts devices without initialising the GPU runtime
+    cmd = launcher_command(n_gpus, argv)
+    print(f"[bench] starting {n_gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=launcher_env(n_gpus, n_dev), stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                    # stdout carries the ONE JSON line of rank 0; stderr passes through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,11 +132,15 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this parent has made no GPU call; it starts the N ranks as a CHILD
+        # process (never an exec), relays their output and exits with the child's code
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
     local = local % max(1, torch.cuda.device_count())       # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -259,6 +299,9 @@ def main():
         }
         if a.n_layers:
             out["invalid"] = "reduced depth (debug run)"
+        if os.environ.get("FVQA_BENCH_REHEARSAL") == "1":
+            out["rehearsal"] = True
+            out["invalid"] = "rehearsal: ranks share devices over gloo (not a scaling measurement)"
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline_leg(a.seq_len, 10)

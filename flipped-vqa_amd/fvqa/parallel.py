@@ -39,15 +39,39 @@ def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, shuffle: 
 class DataParallel(torch.nn.Module):
     """Minimal DDP stand-in: exposes `.module`, forwards calls, and synchronises gradients through
     `sync_grads()` (invoked by the loss scaler right before unscale/step on accumulation
-    boundaries — mathematically identical to DDP's every-backward all-reduce)."""
+    boundaries — mathematically identical to DDP's every-backward all-reduce).
+
+    Like torch DDP at construction (reference train.py:115-117; DDP broadcasts rank 0's module state in its
+    constructor), rank 0's trainable parameters are broadcast to every rank: train.py seeds each rank with
+    seed+rank (train.py:87), so the randomly initialised adapter / projection / temporal parameters would
+    otherwise differ between replicas and the averaged gradient would be applied to different models."""
 
     def __init__(self, module, group=None):
         super().__init__()
         self.module = module
         self.group = group
+        self.broadcast_params()
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+    def _bcast(self, t: torch.Tensor):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(t, src=src, group=self.group)
+
+    def broadcast_params(self):
+        """rank 0's flat trainable buffer -> every rank (one 18 MB broadcast for 7B)."""
+        self._bcast(self.module.flat_params().flat)
+
+    def broadcast_optimizer(self, optimizer, loss_scaler=None):
+        """After a resume: rank 0's AdamW moments / step counter (and loss-scale state) -> every rank, so
+        that replicas stay bitwise identical whatever each rank read from disk."""
+        for t in (optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.step_dev):
+            self._bcast(t)
+        if loss_scaler is not None and getattr(loss_scaler, "_dev", None) is not None:
+            self._bcast(loss_scaler._scale)
+            self._bcast(loss_scaler._tracker)
 
     def sync_grads(self):
         flat = self.module.flat_params()

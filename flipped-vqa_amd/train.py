@@ -135,6 +135,9 @@ def main(args):
     print(optimizer)
     loss_scaler = NativeScaler()
     misc.load_model(args=args, model_without_ddp=model_without_ddp, optimizer=optimizer, loss_scaler=loss_scaler)
+    if args.distributed:                       # whatever each rank loaded, replicas start from rank 0's state
+        model.broadcast_params()
+        model.broadcast_optimizer(optimizer, loss_scaler)
 
     print(f"Start training for {args.epochs} epochs")
     t0 = time.time()

@@ -61,3 +61,56 @@ def test_flat_gradient_allreduce_mean_two_ranks(tmp_path):
 def test_allreduce_is_identity_without_process_group():
     t = torch.arange(5.0)
     assert allreduce_mean_(t.clone()).equal(t)
+
+
+class _Flat:
+    def __init__(self, rank):
+        g = torch.Generator().manual_seed(50 + rank)
+        self.flat = torch.randn(1000, generator=g)
+        self.flat_grad = torch.randn(1000, generator=g)
+
+
+class _Module(torch.nn.Module):
+    def __init__(self, rank):
+        super().__init__()
+        self._f = _Flat(rank)
+
+    def flat_params(self):
+        return self._f
+
+
+class _Opt:
+    def __init__(self, rank):
+        self.exp_avg = torch.full((1000,), float(rank))
+        self.exp_avg_sq = torch.full((1000,), 2.0 * rank)
+        self.step_dev = torch.full((1,), 3.0 + rank)
+
+
+def _dp_worker(rank, world, port, out_dir):
+    from fvqa.parallel import DataParallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _Module(rank)
+    g_local = m.flat_params().flat_grad.clone()
+    net = DataParallel(m)                           # constructor broadcasts rank 0's parameters (as torch DDP does)
+    net.sync_grads()
+    opt = _Opt(rank)
+    net.broadcast_optimizer(opt)
+    torch.save(dict(flat=m.flat_params().flat, grad=m.flat_params().flat_grad, g_local=g_local, m=opt.exp_avg,
+                    v=opt.exp_avg_sq, step=opt.step_dev), os.path.join(out_dir, f"dp{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dataparallel_broadcasts_rank0_state_and_averages_grads(tmp_path):
+    """Replicas seeded seed+rank (reference train.py:87) must still start from ONE set of trainables: DDP broadcasts
+    rank 0's at construction (train.py:115-117); so does fvqa.parallel.DataParallel."""
+    world, port = 2, _free_port()
+    mp.spawn(_dp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "dp0.pt"), torch.load(tmp_path / "dp1.pt")
+    assert torch.equal(r0["flat"], _Flat(0).flat) and torch.equal(r1["flat"], r0["flat"])
+    assert not torch.equal(_Flat(1).flat, _Flat(0).flat)
+    want = (r0["g_local"] + r1["g_local"]) / world
+    assert torch.equal(r0["grad"], want) and torch.equal(r1["grad"], want)
+    for k, v in (("m", 0.0), ("v", 0.0), ("step", 3.0)):
+        assert torch.all(r0[k] == v) and torch.all(r1[k] == v)

@@ -1,0 +1,99 @@
+"""Data-parallel path on the GPU (e): two ranks on ONE MI355X over gloo run train.py's
+wiring — DataParallel (rank-0 broadcast, flat-gradient all-reduce) + NativeScalerWithGradNormCount + FusedAdamW
+on the HIP step. Both ranks must hold bitwise-equal parameters after every step, equal to ONE process that
+averages the two shards' gradients itself; an overflow injected on one rank must make BOTH skip the update.
+Reference: train.py:104-117 (DDP), util/misc.py:220-250 (init), util/misc.py:259-273 (scaler)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(tmp_path, world=2):
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), port,
+                               str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+
+
+def test_two_ranks_stay_bitwise_equal_and_match_single_process_average(tmp_path):
+    from tests import dp_worker as W
+    import util.misc as misc
+    from fvqa import synth
+    from fvqa.optim import FusedAdamW, param_groups_weight_decay
+    from tests.gpu_util import build_model
+
+    world = 2
+    t0, t1 = _run_ranks(tmp_path, world)
+    # replicas: identical start (rank 0's values, although rank 1 was initialised differently) and identical after
+    # every step
+    assert torch.equal(t0["p_init"], t1["p_init"])
+    for i in range(W.N_STEPS):
+        assert torch.equal(t0[f"p{i}"], t1[f"p{i}"]), f"replicas diverged at step {i}"
+        assert t0[f"scale{i}"] == t1[f"scale{i}"] and t0[f"found{i}"] == t1[f"found{i}"]
+    # the overflow step: both ranks saw it, skipped the update, backed the scale off, did not count the step
+    i = W.INF_STEP
+    assert t0[f"found{i}"] == 1.0 and t1[f"found{i}"] == 1.0
+    assert torch.equal(t0[f"p{i}"], t0[f"p{i - 1}"])
+    assert t0[f"scale{i}"] == 0.5 * t0[f"scale{i - 1}"]
+    assert t0[f"step{i}"] == t0[f"step{i - 1}"] and t0[f"step{W.N_STEPS - 1}"] == W.N_STEPS - 1
+    assert not torch.equal(t0[f"p{i + 1}"], t0[f"p{i}"])            # training resumes afterwards
+
+    # ONE process doing both shards and the mean itself (what DDP's all-reduce computes)
+    cfg = synth.preset("tiny", vaq=True, qav=True)
+    model, args = build_model(cfg, torch.float32)
+    W.perturb_trainables(model, seed=1000)                          # rank 0's start
+    flat = model.flat_params()
+    assert torch.equal(flat.flat.cpu(), t0["p_init"])
+    opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=0.01, betas=(0.9, 0.95), flat=flat)
+    scaler = misc.NativeScalerWithGradNormCount()
+    scaler._lazy(flat.flat.device)
+    for i in range(W.N_STEPS):
+        opt.zero_grad()
+        a, b, c = model(synth.make_batch(cfg, seed=W.batch_seed(1, world, i)))
+        ((a + b + c) * scaler._scale).sum().backward()
+        g1 = flat.flat_grad.clone()
+        if i == W.INF_STEP:
+            g1[7] = float("inf")
+        opt.zero_grad()
+        a, b, c = model(synth.make_batch(cfg, seed=W.batch_seed(0, world, i)))
+        opt.grad_sync = lambda: flat.flat_grad.add_(g1).div_(world)
+        scaler(a + b + c, opt, parameters=None, update_grad=True)
+        torch.cuda.synchronize()
+        assert torch.equal(flat.flat.cpu(), t0[f"p{i}"]), f"2-rank result != single-process average at step {i}"
+
+
+def test_bench_self_launches_two_ranks_from_a_plain_shell(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts the ranks itself (child process, before any
+    GPU call) and relays ONE JSON line; on this 1-GPU box the ranks share the device over gloo (marked rehearsal)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n_layers", "2", "--steps",
+                        "2", "--warmup", "1", "--no_cpu_baseline"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    if torch.cuda.device_count() < 2:
+        assert d.get("rehearsal") is True

@@ -195,3 +195,27 @@ def test_gemm_decomposition_plans_are_pinned():
     assert ws(1024, 32000, 4096) == 0                                                         # LM head: 500 tiles, tail too big
     assert ws(3072, 22016, 4096) == 8 * 3072 * 256 * 4                                        # three streams: 1020 + 12 x 8
     assert ws(3072, 11008, 4096) == 8 * 3072 * 256 * 4                                        # W2^T under SwiGLU': 504 + 12 x 8
+
+
+def test_bench_launcher_command_and_env():
+    """bench.py --gpus N from a plain shell: the child command is the driver's own N>1 form, and a box with fewer
+    devices than ranks turns the run into a gloo rehearsal (reference launch: run.sh:20-22 torchrun)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "5", "--warmup", "2"], port=29511, python="python3")
+    assert cmd[:3] == ["python3", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+    c2 = bench.launcher_command(2, [])
+    port = int(c2[c2.index("--master-port") + 1])
+    assert 1024 < port < 65536
+    env = bench.launcher_env(8, 8, env={})
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "FVQA_DIST_BACKEND" not in env
+    env = bench.launcher_env(2, 1, env={})
+    assert env["FVQA_DIST_BACKEND"] == "gloo" and env["FVQA_BENCH_REHEARSAL"] == "1"
+    env = bench.launcher_env(2, 0, env={})                     # no device visible: nothing to rehearse on
+    assert "FVQA_DIST_BACKEND" not in env

@@ -39,13 +39,17 @@ class FusedAdamW(torch.optim.Optimizer):
         self.grad_sync = None                    # set by the data-parallel wrapper
         base = flat.flat.data_ptr()
         self._ranges: List[List[tuple]] = []
+        # parameters that never receive a gradient (gates of layers the engine skips, llama/model.py:338): torch
+        # AdamW leaves a parameter whose .grad is None untouched — no decay, no moments — so they are not stepped
+        idle = set(flat.idle_offsets()) if hasattr(flat, "idle_offsets") else set()
         for g in self.param_groups:
             spans = []
             for p in g["params"]:
                 off = (p.data_ptr() - base) // 4
                 if not (0 <= off and off + p.numel() <= flat.flat.numel()) or p.dtype != torch.float32:
                     raise ValueError("FusedAdamW: parameter is not a view of the flat trainable buffer")
-                spans.append((off, off + p.numel()))
+                if off not in idle:
+                    spans.append((off, off + p.numel()))
                 self.state[p] = {"step": self.step_dev, "exp_avg": self.exp_avg[off:off + p.numel()].view(p.shape),
                                  "exp_avg_sq": self.exp_avg_sq[off:off + p.numel()].view(p.shape)}
             spans.sort()

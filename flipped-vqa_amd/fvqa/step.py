@@ -440,6 +440,13 @@ class FlatParams:
         li = self.model.engine_layer_ids()[i]
         return self.gate_grads[li, 0], self.gate_grads[li, 1]
 
+    def idle_offsets(self):
+        """Flat offsets of the gates of layers the engine never runs (adapter_layer < n_layers): the reference
+        leaves their .grad None, so optimizers must not touch them (no weight decay, no moments)."""
+        live = set(self.model.engine_layer_ids())
+        return [self.offsets[f"layers.{li}.attention.gate{j}"][0]
+                for li in range(len(self.model.layers)) if li not in live for j in (1, 2)]
+
     def attach_grads(self):
         """p.grad <- view of the flat gradient buffer for every trainable."""
         named = dict(self.model.named_parameters())

@@ -101,3 +101,30 @@ def test_checkpoint_roundtrip(tmp_path):
     assert args2.start_epoch == 4
     assert torch.equal(model2.flat_params().flat, model.flat_params().flat)
     assert torch.equal(opt2.exp_avg, opt.exp_avg) and opt2.step_dev.item() == opt.step_dev.item()
+
+
+def test_gates_of_skipped_layers_are_left_alone():
+    """adapter_layer < n_layers: the engine skips the first layers (reference llama/model.py:338), their gates get no
+    gradient in the reference (.grad is None -> torch AdamW neither decays nor moves them)."""
+    cfg, model, args, opt = _setup(adapter_layer=1)          # tiny has 2 layers: layer 0 is skipped
+    assert model.engine_layer_ids() == [1]
+    flat = model.flat_params()
+    named = dict(model.named_parameters())
+    g_idle = [named["layers.0.attention.gate1"], named["layers.0.attention.gate2"]]
+    g_live = [named["layers.1.attention.gate1"], named["layers.1.attention.gate2"]]
+    before_idle = [g.detach().clone() for g in g_idle]
+    before_live = [g.detach().clone() for g in g_live]
+    assert float(before_idle[1].abs().max()) > 0             # gate2 = -bias: weight decay WOULD move it
+    scaler = misc.NativeScalerWithGradNormCount()
+    for g in opt.param_groups:
+        g["lr"] = 0.01
+    for s in range(2):
+        opt.zero_grad()
+        a, b, c = model(synth.make_batch(cfg, seed=3 + s))
+        scaler(a + b + c, opt, parameters=None, update_grad=True)
+    torch.cuda.synchronize()
+    for g, b in zip(g_idle, before_idle):
+        assert torch.equal(g.detach(), b)
+    assert all(not torch.equal(g.detach(), b) for g, b in zip(g_live, before_live))
+    for off in flat.idle_offsets():
+        assert float(opt.exp_avg[off:off + cfg.n_heads].abs().max()) == 0.0

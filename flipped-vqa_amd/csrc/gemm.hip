@@ -208,6 +208,8 @@ int launch_128(const void* A, const void* B, void* C, const void* R, float* tail
 // weight + activation fragments in flight from global memory, no LDS staging), the 8 partial 16x16 blocks meet
 // in LDS. The MFMA is fed the weight strip as its row operand, so a lane ends up with 4 consecutive columns of
 // one row (the same transposed-block trick as the 256x256 epilogue).
+// EPI: none / residual (C = acc + R) / FVQA_EPI_SKINNY_ACC (fp32 C += acc: gradient rows summed into a grad buffer).
+constexpr int FVQA_EPI_SKINNY_ACC = 100;
 template <typename TO, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_skinny(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       TO* __restrict__ C, const bf16_t* __restrict__ R, int M, int N,
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(512) void gemm_nt_skinny(const bf16_t* __restrict__
 #pragma unroll
       for (int ww = 0; ww < 8; ++ww) v += part[ww][m][n];
       if (EPI == FVQA_EPI_RESIDUAL) v += to_f32<bf16_t>(R[(size_t)m * ldc + n0 + n]);
+      if (EPI == FVQA_EPI_SKINNY_ACC) v += to_f32<TO>(C[(size_t)m * ldc + n0 + n]);
       C[(size_t)m * ldc + n0 + n] = from_f32<TO>(v);
     }
   }
@@ -256,6 +259,9 @@ int launch_skinny(const void* A, const void* B, void* C, const void* R, int M, i
   if (epi == FVQA_EPI_RESIDUAL)
     hipLaunchKernelGGL((gemm_nt_skinny<TO, FVQA_EPI_RESIDUAL>), grid, block, 0, st, (const bf16_t*)A,
                        (const bf16_t*)B, (TO*)C, (const bf16_t*)R, M, N, K, lda, ldb, ldc);
+  else if (epi == FVQA_EPI_SKINNY_ACC)
+    hipLaunchKernelGGL((gemm_nt_skinny<TO, FVQA_EPI_SKINNY_ACC>), grid, block, 0, st, (const bf16_t*)A,
+                       (const bf16_t*)B, (TO*)C, (const bf16_t*)R, M, N, K, lda, ldb, ldc);
   else
     hipLaunchKernelGGL((gemm_nt_skinny<TO, FVQA_EPI_NONE>), grid, block, 0, st, (const bf16_t*)A, (const bf16_t*)B,
                        (TO*)C, (const bf16_t*)R, M, N, K, lda, ldb, ldc);
@@ -266,6 +272,9 @@ int launch_skinny(const void* A, const void* B, void* C, const void* R, int M, i
 }  // namespace
 
 #define FVQA_GEMM256_DEFAULT_MODE 6
+extern "C" size_t fvqa_gemm_sk_workspace(void);
+int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
+                      int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st);
 int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, float* tail, void* ws,
                           size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
                           int out_dtype, int epilogue, int force_splits, int mode, hipStream_t st);
@@ -275,11 +284,12 @@ int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, 
 // loop; 4 = 256x256 plain 64-byte-row ring loop;
 // 7 = 256x256 wide-row (128-byte) two-stage ring; 8 = wide-row asymmetric rings (A x2, B x3, role-split DMA); 9 = the same with waves 4-7 staggered by half a stage (the default loop, tile width chosen per problem);
 // 10 / 11 = the default loop with the tile forced 192 / 256 columns wide; 12 = the skinny (M <= 16) decode kernel;
+// 13 = the work-balanced persistent kernel (gemm_sk.hip; what variant 0 picks for large problems);
 // 16+s = 256x256 default loop with exactly s K-splits (tests / tuning).
 extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail, int M, int N,
                             int K, int lda, int ldb, int ldc, int m_split, int dtype, int out_dtype, int epilogue,
                             int variant, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!A || !B || (!C && epilogue != FVQA_EPI_PARTIAL)) return FVQA_EINVAL;
+  if (!A || !B || (!C && epilogue != FVQA_EPI_PARTIAL && !(tail && m_split == 0))) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype) || !fvqa_dtype_ok(out_dtype)) return FVQA_EINVAL;
   if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_PARTIAL &&
       epilogue != FVQA_EPI_SWIGLU_BWD)
@@ -295,12 +305,33 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
     return FVQA_EALIGN;
   if (lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
+  // the work-balanced persistent kernel (gemm_sk.hip) takes every large problem whose output rows it can store in
+  // whole 16-byte chunks; the first 4 KiB of the workspace are its epoch flags (zeroed once by the caller), so the
+  // older split-K paths below get the workspace past them
+  const size_t sync_bytes = 4096;
+  const bool sk_ok = epilogue != FVQA_EPI_PARTIAL && tail == nullptr && (N & 7) == 0 && (ldc & 7) == 0 && C &&
+                     (((uintptr_t)C | (uintptr_t)R) & 15) == 0 && workspace != nullptr &&
+                     ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace();
+  if (variant == 13 && !sk_ok) return FVQA_EALIGN;
+  if (variant == 13 || (variant == 0 && sk_ok && M >= 192 && N >= 256))
+    return fvqa_gemm_sk_impl(A, B, C, R, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, dtype, out_dtype, epilogue, st);
+  if (workspace != nullptr && workspace_bytes > sync_bytes) {
+    workspace = (char*)workspace + sync_bytes;
+    workspace_bytes -= sync_bytes;
+  } else {
+    workspace = nullptr;
+    workspace_bytes = 0;
+  }
   const bool big = epilogue == FVQA_EPI_PARTIAL || epilogue == FVQA_EPI_SWIGLU_BWD || (variant >= 3 && variant <= 11 && variant != 5 && variant != 6) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
   if (big) {
     const int mode = variant == 4 ? 0 : variant == 7 ? 2 : variant == 8 ? 3 : variant == 9 ? 6 : variant == 10 ? 63 : variant == 11 ? 61 : FVQA_GEMM256_DEFAULT_MODE;
     return fvqa_gemm_nt_256_impl(A, B, C, R, tail, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, m_split, dtype,
                                  out_dtype, epilogue, variant >= 16 ? variant - 16 : 0, mode, st);
   }
+  // every row goes to the fp32 tail (m_split == 0): the decode-shape kernel accumulates straight into it
+  if (dtype == FVQA_BF16 && M <= 16 && (K % 256) == 0 && tail != nullptr && m_split == 0 && epilogue == FVQA_EPI_NONE &&
+      (variant == 0 || variant == 12))
+    return launch_skinny<float>(A, B, tail, nullptr, M, N, K, lda, ldb, N, FVQA_EPI_SKINNY_ACC, st);
   const bool skinny_ok = dtype == FVQA_BF16 && M <= 16 && (K % 256) == 0 && tail == nullptr &&
                          (epilogue == FVQA_EPI_NONE || epilogue == FVQA_EPI_RESIDUAL);
   if (variant == 12 && !skinny_ok) return FVQA_ESHAPE;

@@ -21,7 +21,7 @@
 // 256 CUs) are split along K over blockIdx ranges; partial sums go to an fp32 workspace
 // [split][M][N] and `splitk_fixup` adds them (+ residual, fp32 tail rows) in one pass.
 #include "common.h"
-#include <vector>
+#include "probe.h"
 
 namespace {
 
@@ -856,25 +856,6 @@ __global__ __launch_bounds__(256) void splitk_fixup(const float* __restrict__ ws
   }
 }
 
-// ---- measurement probe (include/fvqa.h: fvqa_gemm_timing_*)
-struct TimingRec { hipEvent_t e0, e1; double flops; int kind; };
-static std::vector<TimingRec> g_timing;
-static bool g_timing_on = false;
-struct TimingScope {
-  hipStream_t st; bool on; TimingRec r;
-  TimingScope(hipStream_t s, double flops, int kind) : st(s), on(g_timing_on) {
-    if (!on) return;
-    r.flops = flops; r.kind = kind;
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
-    (void)hipEventRecord(r.e0, st);
-  }
-  ~TimingScope() {
-    if (!on) return;
-    (void)hipEventRecord(r.e1, st);
-    g_timing.push_back(r);
-  }
-};
-
 template <typename T, typename TO, int EPI, int PIPE, int NT = 4>
 int launch_256(const void* A, const void* B, void* C, const void* R, float* tail, float* ws, int M, int N, int K,
                int lda, int ldb, int ldc, int m_split, int splits, bool partial_only, hipStream_t st) {
@@ -889,7 +870,7 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
     {
-      TimingScope ts(st, 2.0 * M * N * K, EPI | 16 | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
+      FvqaProbeScope ts(st, 2.0 * M * N * K, EPI | 16 | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
       hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
                          lda, ldb, ldc, m_split, tm, splits);
     }
@@ -904,7 +885,7 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
     auto k = gemm_nt_256<T, TO, EPI, false, PIPE, NT>;
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr_done = true; }
-    TimingScope ts(st, 2.0 * M * N * K, EPI | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
+    FvqaProbeScope ts(st, 2.0 * M * N * K, EPI | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
     hipLaunchKernelGGL(k, grid, block, LDSB, st, (const T*)A, (const T*)B, (TO*)C, (const T*)R, tail, ws, M, N, K,
                        lda, ldb, ldc, m_split, tm, 1);
   }
@@ -913,32 +894,6 @@ int launch_256(const void* A, const void* B, void* C, const void* R, float* tail
 }
 
 }  // namespace
-
-extern "C" int fvqa_gemm_timing_enable(int on) {
-  for (auto& r : g_timing) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-  g_timing.clear();
-  g_timing_on = on != 0;
-  return FVQA_OK;
-}
-
-extern "C" int fvqa_gemm_timing_read(int max, float* us, double* flops, int* kind) {
-  const int n = (int)g_timing.size();
-  if (max <= 0) return n;                               // size query: record untouched
-  for (int i = 0; i < n; ++i) {
-    TimingRec& r = g_timing[i];
-    float ms = 0.f;
-    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
-    if (i < max) {
-      if (us) us[i] = ms * 1e3f;
-      if (flops) flops[i] = r.flops;
-      if (kind) kind[i] = r.kind;
-    }
-    (void)hipEventDestroy(r.e0);
-    (void)hipEventDestroy(r.e1);
-  }
-  g_timing.clear();
-  return n;
-}
 
 // how many K splits the 256-tile path uses for an (M, N, K) problem on a 256-CU part
 extern "C" int fvqa_gemm_splits(int M, int N, int K, int dtype) {
@@ -980,11 +935,20 @@ static TailPlan tail_plan(int M, int N, int K, int dtype) {
   return p;
 }
 
+extern "C" size_t fvqa_gemm_sk_workspace(void);
+// bytes that serve every path fvqa_gemm_nt may take for the problem: the persistent kernel's flags + slabs, or
+// the split-K planes of the older paths behind the 4 KiB flag block
 extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
   const int s = fvqa_gemm_splits(M, N, K, dtype);
-  if (s > 1) return (size_t)s * M * N * sizeof(float);
-  const TailPlan p = tail_plan(M, N, K, dtype);
-  return p.sr > 1 ? (size_t)p.sr * M * (N - p.n1) * sizeof(float) : 0;
+  size_t old_path = 0;
+  if (s > 1) old_path = (size_t)s * M * N * sizeof(float);
+  else {
+    const TailPlan p = tail_plan(M, N, K, dtype);
+    old_path = p.sr > 1 ? (size_t)p.sr * M * (N - p.n1) * sizeof(float) : 0;
+  }
+  old_path += 4096;
+  const size_t sk = (M >= 192 && N >= 256) ? fvqa_gemm_sk_workspace() : 0;
+  return old_path > sk ? old_path : sk;
 }
 
 // Tile width for an unsplit problem on 256 CUs: rounds x work per tile, 256-wide (with its tail-round

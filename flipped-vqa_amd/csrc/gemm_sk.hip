@@ -1,0 +1,398 @@
+// Persistent 256-row projection GEMM for gfx950: a grid of at most one 512-thread workgroup per CU walks whole
+// 256 x 256 output tiles with the LDS-DMA ring loop of gemm256_loop.h; where a round of whole tiles would leave more
+// than half the CUs idle (N = 4096 outputs: 64 tiles for 256 CUs; the last round of W1|W3) the tiles of that round are
+// split along K over 2, 4 or 8 workgroups, which reduce them INSIDE the launch and store the finished tile once, with
+// the epilogue (residual add, SwiGLU', fp32 logits) applied there. Replaces, for every F.linear of the step (reference
+// llama/model.py:89,127-128,142,348 and their dX), "split-K planes in HBM + a consumer or a fix-up pass that sums
+// them". Partition rules: gemm_sk_plan.h.
+//
+// Hand-off of a partial tile (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1 hand-off table;
+// cdna_hip_programming.md G16 R1):
+//   producer: every wave stores the accumulator blocks it does not reduce itself to its workgroup's slab with 16-byte
+//             WRITE-THROUGH (sc1) stores in register-image order (1 KiB contiguous per wave instruction = whole
+//             128-byte lines), s_waitcnt vmcnt(0) in EVERY wave, workgroup barrier, then ONE lane stores the launch
+//             epoch to the workgroup's flag with an agent-scope atomic (sc1) store;
+//   consumer: ONE lane polls each partner's flag (relaxed agent-scope sc1 load, bounded spin), workgroup barrier, then
+//             every wave reads the partners' slabs with sc1 loads ONLY (they bypass this CU's L1; -DFVQA_SK_ACQUIRE
+//             adds the agent-scope acquire fence the general recipe has).
+// Results do not depend on dispatch order or XCD placement; every sum runs in piece order 0..s-1, so outputs are
+// bitwise repeatable. A workgroup waits only for equal partners that have done the same work before and publish
+// before they wait; the grid never exceeds the CU count (160 KiB of LDS = one workgroup per CU), so every workgroup
+// is resident. A spin that runs out (~1 s) raises the error word of the workspace and lets the grid drain.
+#include "gemm256_loop.h"
+#include "gemm_sk_plan.h"
+#include "probe.h"
+#include <atomic>
+
+namespace {
+using namespace fvqa_ring;
+
+typedef unsigned long long u64;
+constexpr int SLAB_FLOATS = 8 * 32 * 256;            // 8 waves x 32 blocks x (64 lanes x 4) = 256 KiB
+constexpr size_t SYNC_BYTES = 4096;                   // u64 words: [0] error, [1 + workgroup] epoch flags (<= 511)
+
+struct SkArgs {
+  const void* A; const void* B; void* C; const void* R;
+  float* slabs; u64* sync; u64* stamps;
+  int M, N, K, lda, ldb, ldc;
+  u64 epoch;
+  fvqa_sk_plan plan;
+};
+
+__device__ __forceinline__ int xcd_chunk(int bid, int nwg) {     // consecutive work ids share an XCD (bijective)
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& q, float (&v)[8]) {
+  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xFFFF0000u);
+  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xFFFF0000u);
+  v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xFFFF0000u);
+  v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  uint4 t;
+  t.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+  t.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+  t.z = (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16);
+  t.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
+  return t;
+}
+
+// Tuning builds (-DFVQA_SK_STAMPS): 100 MHz timestamps of each workgroup's phases, 16 u64 words per workgroup behind the
+// slabs (never read by the kernel; tools/sk_check.py prints them). The shipping build compiles none of it.
+#ifdef FVQA_SK_STAMPS
+#define SK_STAMP(slot) do { if (threadIdx.x == 0 && (slot) < 16) a.stamps[(size_t)wid * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SK_STAMP(slot) do { } while (0)
+#endif
+
+// Bounded relaxed poll of one epoch flag by the calling lane.
+__device__ __forceinline__ bool wait_epoch(u64* flag, u64 epoch, u64* err) {
+  for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_fetch_or(err, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+// Final store of register blocks [0, n_own) (16 rows each) of every wave's 128 x 64 sub-tile; register block i holds
+// tile row block i ^ (rowxor / 16). The accumulators take one round trip through the wave's private 16 KiB of (idle)
+// ring LDS so that every store instruction writes whole 128-byte lines: chunk c of row r sits at chunk c ^ (r & 15),
+// conflict-free for the fragment writes and the row reads.
+//   4-byte outputs: lane k of a row owns columns 4k..4k+3 and 32+4k..32+4k+3; 2-byte outputs: columns 8k..8k+7.
+template <typename T, typename TO, int EPI>
+__device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const SkArgs& a, int m0, int n0, int w,
+                                           int lane, int n_own, int rowxor) {
+  constexpr bool W4 = sizeof(TO) == 4;
+  const int wr = w >> 2, wc = w & 3;
+  const int crow = lane & 15;
+  float* stg = reinterpret_cast<float*>(smem) + w * (64 * 64);
+  const int q = lane >> 3, k = lane & 7;
+  const int rl = W4 ? ((q & 1) * 8 + (q >> 1)) : q;
+  const int cA = W4 ? k : 2 * k, cB = W4 ? 8 + k : 2 * k + 1;
+  const int N = a.N, M = a.M, ldc = a.ldc;
+  const int nA = n0 + wc * 64 + cA * 4, nB = n0 + wc * 64 + cB * 4;
+  const T* R = (const T*)a.R;
+  TO* C = (TO*)a.C;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (n_own <= 4 * p) continue;                                       // wave-uniform
+    auto row_of = [&](int t) { return W4 ? 16 * (t >> 1) + 4 * (t & 1) + rl : 8 * t + rl; };
+    auto live = [&](int t) { return 4 * p + (t >> 1) < n_own; };
+    auto grow = [&](int t) { return m0 + wr * 128 + ((p * 64 + row_of(t)) ^ rowxor); };     // output row
+    uint4 qa[8], qb[8];
+    if constexpr (sizeof(T) == 2 && (EPI == FVQA_EPI_SWIGLU_BWD || EPI == FVQA_EPI_RESIDUAL)) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {                                   // epilogue operands in flight before the staging
+        const int m = grow(t);
+        qa[t] = qb[t] = uint4{0u, 0u, 0u, 0u};
+        if (live(t) && m < M && nA < N) {
+          if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
+            const T* rp = R + (size_t)m * ldc + nA;                   // ab rows: a | b halves, b at +ldc/2
+            qa[t] = *reinterpret_cast<const uint4*>(rp);
+            qb[t] = *reinterpret_cast<const uint4*>(rp + (ldc >> 1));
+          } else {
+            qa[t] = *reinterpret_cast<const uint4*>(R + (size_t)m * ldc + nA);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(stg + (ii * 16 + crow) * 64 + (((j * 4 + (lane >> 4)) ^ crow) << 2)) = acc[p * 4 + ii][j];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = row_of(t);
+      const int m = grow(t);
+      float v[8];
+      {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * 64 + ((cA ^ (r & 15)) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * 64 + ((cB ^ (r & 15)) << 2));
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      }
+      if (!live(t) || m >= M) continue;
+      float(&vA)[4] = reinterpret_cast<float(&)[4]>(v[0]);
+      float(&vB)[4] = reinterpret_cast<float(&)[4]>(v[4]);
+      if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
+        // v = dz[m][n..]; R = ab (rows of 2N: a | b); C = dab (rows of 2N): d(silu(a)*b)   (llama/model.py:142 backward)
+        const size_t o = (size_t)m * ldc;
+        const int hb_ = ldc >> 1;
+        float a_[8], b_[8], da[8], db[8];
+        if constexpr (sizeof(T) == 2) {
+          if (nA >= N) continue;
+          unpack8(qa[t], a_);
+          unpack8(qb[t], b_);
+        } else {
+          if (nA < N) { Vec4<T>::load(R + o + nA, reinterpret_cast<float(&)[4]>(a_[0]));
+                        Vec4<T>::load(R + o + hb_ + nA, reinterpret_cast<float(&)[4]>(b_[0])); }
+          if (nB < N) { Vec4<T>::load(R + o + nB, reinterpret_cast<float(&)[4]>(a_[4]));
+                        Vec4<T>::load(R + o + hb_ + nB, reinterpret_cast<float(&)[4]>(b_[4])); }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sg = 1.f / (1.f + __expf(-a_[e]));
+          da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
+          db[e] = v[e] * a_[e] * sg;
+        }
+        if constexpr (sizeof(TO) == 2) {
+          *reinterpret_cast<uint4*>(C + o + nA) = pack8(da);
+          *reinterpret_cast<uint4*>(C + o + hb_ + nA) = pack8(db);
+        } else {
+          if (nA < N) { Vec4<TO>::store(C + o + nA, reinterpret_cast<float(&)[4]>(da[0]));
+                        Vec4<TO>::store(C + o + hb_ + nA, reinterpret_cast<float(&)[4]>(db[0])); }
+          if (nB < N) { Vec4<TO>::store(C + o + nB, reinterpret_cast<float(&)[4]>(da[4]));
+                        Vec4<TO>::store(C + o + hb_ + nB, reinterpret_cast<float(&)[4]>(db[4])); }
+        }
+      } else {
+        TO* cp = C + (size_t)m * ldc;
+        if constexpr (EPI == FVQA_EPI_RESIDUAL) {
+          float r_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if constexpr (sizeof(T) == 2) {
+            unpack8(qa[t], r_);
+          } else {
+            if (nA < N) Vec4<T>::load(R + (size_t)m * ldc + nA, reinterpret_cast<float(&)[4]>(r_[0]));
+            if (nB < N) Vec4<T>::load(R + (size_t)m * ldc + nB, reinterpret_cast<float(&)[4]>(r_[4]));
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r_[e];
+        }
+        if constexpr (sizeof(TO) == 2) {
+          if (nA < N) *reinterpret_cast<uint4*>(cp + nA) = pack8(v);
+        } else {
+          if (nA < N) Vec4<TO>::store(cp + nA, vA);
+          if (nB < N) Vec4<TO>::store(cp + nB, vB);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Split-K tile shared by NP workgroups (piece c = this one): publish the register blocks [OWN, 8) of the partial tile,
+// fetch blocks of the OWN = 8/NP row blocks this piece reduces from the NP-1 partners, add the NP partials in piece
+// order. Thanks to the row permutation (rowxor = c*OWN*16) the reduced rows are ALWAYS register blocks [0, OWN): the
+// compiler sees the published accumulators die at the stores, so all (NP-1)*OWN*4 partner loads are in flight at once.
+template <int NP>
+__device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs& a, int wid, int c, int team0, int jm,
+                                                int w, int lane, int tid) {
+  constexpr int OWN = 8 / NP;
+  const unsigned lane_off = (unsigned)(w * 32 * 1024 + lane * 16);   // this lane's 16 bytes of block 0 in a slab
+  {
+    float* my = a.slabs + (size_t)wid * SLAB_FLOATS;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+    for (int i = OWN; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                               lane_off + (unsigned)((i * 4 + j) * 1024), 0, 16);     // aux 16 = sc1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
+  }
+  __syncthreads();                                        // (also: every wave is done reading the ring)
+  SK_STAMP(2);
+  const int ts = a.plan.ts;
+  if (tid == 0) {
+    __hip_atomic_store(a.sync + 1 + wid, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int p = 0; p < NP; ++p)
+      if (p != c) (void)wait_epoch(a.sync + 1 + (team0 + p) * ts + jm, a.epoch, a.sync);
+#ifdef FVQA_SK_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // not needed while EVERY load of a partner's slab is an sc1 load
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
+#endif
+  }
+  __syncthreads();
+  SK_STAMP(3);
+  u32x4 x[NP - 1][OWN * 4];
+#pragma unroll
+  for (int q = 0; q < NP - 1; ++q) {
+    const int p = q < c ? q : q + 1;                      // partner piece
+    const float* sl = a.slabs + (size_t)((team0 + p) * ts + jm) * SLAB_FLOATS;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sl), 0, SLAB_FLOATS * 4, 0x00020000);
+    // my tile row block c*OWN + i sits in partner p's register block ((c ^ p) * OWN + i)
+    const unsigned boff = lane_off + (unsigned)(((c ^ p) * OWN) * 4 * 1024);
+#pragma unroll
+    for (int b = 0; b < OWN * 4; ++b) x[q][b] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff + (unsigned)(b * 1024), 0, 16);
+  }
+#pragma unroll
+  for (int b = 0; b < OWN * 4; ++b) {
+    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NP - 1; ++q) {                    // pieces in K order: 0, 1, ..., NP-1 (own partial at position c)
+      if (q == c) sum += acc[b >> 2][b & 3];
+      sum += __builtin_bit_cast(f32x4, x[q][b]);
+    }
+    if (c == NP - 1) sum += acc[b >> 2][b & 3];
+    acc[b >> 2][b & 3] = sum;
+  }
+}
+
+template <typename T, typename TO, int EPI>
+__global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KE = Mma<T>::KE;
+  const fvqa_sk_plan& P = a.plan;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = xcd_chunk(blockIdx.x, gridDim.x);
+  const int g = wid / P.ts, jm = wid - g * P.ts;
+  SK_STAMP(0);
+  fvqa_sk_seg s;
+  for (int idx = 0; fvqa_sk_segment(P, g, idx, &s); ++idx) {
+    const int tni = s.tile / P.mgroups, mg = s.tile - tni * P.mgroups;
+    const int mt = mg * P.ts + jm;
+    if (mt >= P.tm) continue;                             // m group with fewer tiles than the team has members
+    const int m0 = mt * TM, n0 = tni * 256;
+    const int own = 8 / s.n;                              // register blocks this piece reduces and stores
+    const int rowxor = s.n > 1 ? s.c * own * 16 : 0;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ring_loop<T, 4>(acc, smem, (const T*)a.A, (const T*)a.B, a.M, a.N, a.lda, a.ldb, m0, n0,
+                    (size_t)s.k0 * 2 * KE, s.k1 - s.k0, w, lane, rowxor);
+    SK_STAMP(1);
+    // Everything below is addressed from opaque copies of (lane, wave, tile origin): otherwise hipcc hoists the
+    // epilogue's per-lane address arithmetic above the ring loop and pays for it with spills INSIDE that loop.
+    int lane_e = lane, w_e = w, m0_e = m0, n0_e = n0;
+    asm volatile("" : "+v"(lane_e), "+s"(w_e), "+s"(m0_e), "+s"(n0_e));
+    const int tid_e = w_e * 64 + lane_e;
+    if (s.n == 1) __syncthreads();                        // every wave is done reading the ring
+    else {
+      const int team0 = g - s.c;                          // team holding piece 0 of this tile
+      if (s.n == 2) exchange_reduce<2>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
+      else if (s.n == 4) exchange_reduce<4>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
+      else exchange_reduce<8>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
+    }
+    SK_STAMP(4);
+    store_tile<T, TO, EPI>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);
+    __syncthreads();                                      // staging reads done before the next segment's DMA
+    SK_STAMP(5);
+  }
+}
+
+std::atomic<unsigned long long> g_epoch{0};
+
+template <typename T, typename TO, int EPI>
+int launch_sk(const SkArgs& a, hipStream_t st) {
+  auto k = gemm_sk_256<T, TO, EPI>;
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done.load()) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
+    attr_done.store(true);
+  }
+  {
+    FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (a.plan.s > 1 ? 16 : 0) | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
+    hipLaunchKernelGGL(k, dim3(a.plan.n_teams * a.plan.ts), dim3(512), RING_BYTES, st, a);
+  }
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+int cu_count() {
+  static std::atomic<int> n{0};
+  int v = n.load();
+  if (v > 0) return v;
+  int dev = 0;
+  hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0)
+    return 256;                                           // MI355X; also what the host-only plan queries assume
+  n.store(pr.multiProcessorCount);
+  return pr.multiProcessorCount;
+}
+
+}  // namespace
+
+constexpr size_t STAMP_BYTES = 256 * 16 * sizeof(u64);
+extern "C" size_t fvqa_gemm_sk_workspace(void) {
+  return SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float) + STAMP_BYTES;
+}
+
+extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
+                                     int32_t* segs_out, int max_segs) {
+  if (M <= 0 || N <= 0 || K <= 0 || !fvqa_dtype_ok(dtype) || n_cu <= 0) return FVQA_EINVAL;
+  const int wide = dtype == FVQA_BF16 ? 64 : 32;
+  if (K % wide) return FVQA_ESHAPE;
+  const fvqa_sk_plan p = fvqa_sk_make_plan(M, N, K, wide, n_cu);
+  if (plan_out) {
+    const int32_t v[11] = {p.tm, p.tn, p.nw_tile, p.gran, p.gpt, p.ts, p.mgroups, p.n_teams, p.full, p.rem, p.s};
+    for (int i = 0; i < 11; ++i) plan_out[i] = v[i];
+  }
+  int n = 0;
+  if (team >= 0 && team < p.n_teams) {
+    fvqa_sk_seg s;
+    for (int idx = 0; fvqa_sk_segment(p, team, idx, &s); ++idx) {
+      if (segs_out && n < max_segs) {
+        const int32_t v[5] = {s.tile, s.k0, s.k1, s.n, s.c};
+        for (int i = 0; i < 5; ++i) segs_out[n * 5 + i] = v[i];
+      }
+      ++n;
+    }
+  }
+  return n;
+}
+
+// C[M,N] = A[M,K] x B[N,K]^T with the epilogue applied once per finished tile. `ws`: fvqa_gemm_sk_workspace()
+// bytes whose first 4096 were zeroed once by the caller after allocation (epoch flags; never reset afterwards).
+int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
+                      int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st) {
+  if (!ws || ws_bytes < fvqa_gemm_sk_workspace() || ((uintptr_t)ws & 255)) return FVQA_EALIGN;
+  const int n_cu = cu_count();
+  SkArgs a;
+  a.A = A; a.B = B; a.C = C; a.R = R;
+  a.sync = (u64*)ws;
+  a.slabs = (float*)((char*)ws + SYNC_BYTES);
+  a.stamps = (u64*)((char*)ws + SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float));
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.plan = fvqa_sk_make_plan(M, N, K, dtype == FVQA_BF16 ? 64 : 32, n_cu < 256 ? n_cu : 256);
+  if (a.plan.n_teams * a.plan.ts > 256 || a.plan.n_teams * a.plan.ts > n_cu) return FVQA_ESHAPE;
+  a.epoch = g_epoch.fetch_add(1) + 1;
+#define SK(T, TO)                                                                             \
+  switch (epilogue) {                                                                         \
+    case FVQA_EPI_NONE: return launch_sk<T, TO, FVQA_EPI_NONE>(a, st);                        \
+    case FVQA_EPI_RESIDUAL: return launch_sk<T, TO, FVQA_EPI_RESIDUAL>(a, st);                \
+    case FVQA_EPI_SWIGLU_BWD: return launch_sk<T, TO, FVQA_EPI_SWIGLU_BWD>(a, st);            \
+    default: return FVQA_EINVAL;                                                              \
+  }
+  if (dtype == FVQA_BF16) {
+    if (out_dtype == FVQA_F32) {
+      if (epilogue != FVQA_EPI_NONE) return FVQA_EINVAL;
+      return launch_sk<bf16_t, float, FVQA_EPI_NONE>(a, st);
+    }
+    SK(bf16_t, bf16_t)
+  }
+  SK(float, float)
+#undef SK
+}

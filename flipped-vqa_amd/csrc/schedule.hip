@@ -7,12 +7,13 @@
 // launch stream no longer depends on the speed of the Python interpreter.
 //
 // Sequence per layer (reference llama/model.py:184-187 with Attention :87-128, FeedForward :141-142):
-//   fwd: [xn = RMSNorm(x)] -> adapter rows -> QKV GEMM -> RoPE -> attention -> WO GEMM (split-K
-//        partials) -> fused residual+RMSNorm -> W1|W3 GEMM -> SwiGLU -> W2 GEMM (partials) -> fused
-//        residual+RMSNorm of the NEXT layer (or the final norm)
-//   bwd: W2^T GEMM with SwiGLU' epilogue -> W1|W3^T GEMM (partials) -> fused RMSNorm' (+residual grad) ->
-//        WO^T GEMM -> attention' -> RoPE^-1 -> QKV^T GEMM (partials, adapter-gradient tail rows) ->
-//        fused RMSNorm' (+residual grad)
+//   fwd: [xn = RMSNorm(x)] -> QKV GEMM on the sequence rows + the A adapter rows through the decode-shape kernel
+//        (their K/V projections, model.py:98-100) -> attention (RoPE inside) -> WO GEMM + residual (split-K reduced
+//        inside the launch) -> RMSNorm -> W1|W3 GEMM -> SwiGLU -> W2 GEMM + residual -> RMSNorm of the NEXT layer
+//        (or the final norm)
+//   bwd: W2^T GEMM with SwiGLU' epilogue -> W1|W3^T GEMM -> RMSNorm' (+residual grad) -> WO^T GEMM -> attention'
+//        -> QKV^T GEMM on the sequence rows -> RMSNorm' (+residual grad); the adapter rows of dqkv go through the
+//        decode-shape kernel straight into the fp32 adapter-query gradient (+=)
 #include "common.h"
 
 extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p);
@@ -45,6 +46,7 @@ int check_plan(const fvqa_layer_plan* p) {
       !p->o || !p->lse_a || !p->lse_t || !p->h || !p->ab || !p->xn || !p->hn || !p->z || !p->xnf || !p->rstdN ||
       !p->cos_t || !p->sin_t || !p->vstart || !p->gemm_ws)
     return FVQA_EINVAL;
+  if ((uintptr_t)p->gemm_ws & 255) return FVQA_EALIGN;
   return FVQA_OK;
 }
 
@@ -52,18 +54,16 @@ int check_plan(const fvqa_layer_plan* p) {
 
 extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p) {
   if (check_plan_dims_only(p)) return 0;
-  const int dt = p->dtype, D = p->dim, Hf = p->hidden, R = p->n_seq * p->seq_len, Ra = R + p->adapter_len;
+  const int dt = p->dtype, D = p->dim, Hf = p->hidden, R = p->n_seq * p->seq_len;
   size_t need = 0;
   auto upd = [&](size_t v) { if (v > need) need = v; };
-  auto part = [&](int M, int N, int K) { return (size_t)fvqa_gemm_splits(M, N, K, dt) * M * N * sizeof(float); };
-  upd(fvqa_gemm_workspace(Ra, 3 * D, D, dt));       // QKV
-  upd(part(R, D, D));                                // WO partials
-  upd(fvqa_gemm_workspace(R, 2 * Hf, D, dt));        // W1|W3
-  upd(part(R, D, Hf));                               // W2 partials
-  upd(fvqa_gemm_workspace(R, Hf, D, dt));            // W2^T
-  upd(part(R, D, 2 * Hf));                           // W1|W3^T partials
-  upd(fvqa_gemm_workspace(R, D, D, dt));             // WO^T
-  upd(part(Ra, D, 3 * D));                           // QKV^T partials
+  upd(fvqa_gemm_workspace(R, 3 * D, D, dt));        // QKV
+  upd(fvqa_gemm_workspace(R, D, D, dt));            // WO, WO^T
+  upd(fvqa_gemm_workspace(R, 2 * Hf, D, dt));       // W1|W3
+  upd(fvqa_gemm_workspace(R, D, Hf, dt));           // W2
+  upd(fvqa_gemm_workspace(R, Hf, D, dt));           // W2^T
+  upd(fvqa_gemm_workspace(R, D, 2 * Hf, dt));       // W1|W3^T
+  upd(fvqa_gemm_workspace(R, D, 3 * D, dt));        // QKV^T
   return need;
 }
 
@@ -73,8 +73,10 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
   const int A = p->adapter_len, S = p->seq_len, n_seq = p->n_seq;
   const int R = n_seq * S, Ra = R + A;
   const size_t es = fvqa_dtype_size(dt);
-  char* xn_tail = at(p->xn, (size_t)R * D, es);
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
+  if (!p->adapter_c) return FVQA_EINVAL;
+  // the adapter prompts of all walked layers in storage dtype (model.py:339 `.half()`), one launch
+  RUN(fvqa_cast_rows(p->adapter, p->adapter_c, L * A, D, dt, stream));
   RUN(fvqa_rmsnorm_fwd(p->xs, p->an[0], p->xn, p->rstd1, R, D, p->eps, dt, stream));
   for (int i = 0; i < L; ++i) {
     const void* x = at(p->xs, (size_t)i * R * D, es);
@@ -85,9 +87,11 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
     float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
     float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
-    if (i == 0) RUN(fvqa_cast_rows(p->adapter, xn_tail, A, D, dt, stream));   // later layers: in the norm kernel
-    RUN(fvqa_gemm_nt(p->xn, p->wqkv[i], qkv, nullptr, nullptr, Ra, 3 * D, D, D, D, 3 * D, Ra, dt, dt, FVQA_EPI_NONE, 0,
+    RUN(fvqa_gemm_nt(p->xn, p->wqkv[i], qkv, nullptr, nullptr, R, 3 * D, D, D, D, 3 * D, R, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
+    // adapter rows ride under the sequence rows of qkv: their projections stream the (cache-warm) weights once more
+    RUN(fvqa_gemm_nt(at(p->adapter_c, (size_t)i * A * D, es), p->wqkv[i], at(qkv, (size_t)R * 3 * D, es), nullptr,
+                     nullptr, A, 3 * D, D, D, D, 3 * D, A, dt, dt, FVQA_EPI_NONE, 0, nullptr, 0, stream));
     if (fused_rope) {                                  // bf16 MFMA build: q,k stay raw and are rotated inside
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t, n_seq, S, H, Dh,
                         A, p->max_feats, dt, stream));
@@ -96,26 +100,20 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, nullptr, nullptr, n_seq, S, H, Dh, A,
                         p->max_feats, dt, stream));
     }
-    // WO: split-K partials summed by the fused residual + ffn-norm kernel
-    int sp = fvqa_gemm_splits(R, D, D, dt);
-    RUN(fvqa_gemm_nt(o, p->wo[i], nullptr, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_PARTIAL, 0,
-                     p->gemm_ws, p->gemm_ws_bytes, stream));
-    RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, x, p->fn[i], h, p->hn,
-                                p->rstd2 + (size_t)i * R, R, D, p->eps, nullptr, 0, dt, stream));
+    // h = x + o·Wo^T (model.py:185), hn = RMSNorm(h)·w
+    RUN(fvqa_gemm_nt(o, p->wo[i], h, x, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
+                     p->gemm_ws_bytes, stream));
+    RUN(fvqa_rmsnorm_fwd(h, p->fn[i], p->hn, p->rstd2 + (size_t)i * R, R, D, p->eps, dt, stream));
     RUN(fvqa_gemm_nt(p->hn, p->w13[i], ab, nullptr, nullptr, R, 2 * Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
     RUN(fvqa_swiglu_fwd(ab, p->z, R, Hf, dt, stream));
-    sp = fvqa_gemm_splits(R, D, Hf, dt);
-    RUN(fvqa_gemm_nt(p->z, p->w2[i], nullptr, nullptr, nullptr, R, D, Hf, Hf, Hf, D, R, dt, dt, FVQA_EPI_PARTIAL, 0,
+    // x_next = h + z·W2^T (model.py:186), then the next layer's attention norm (or the final norm)
+    RUN(fvqa_gemm_nt(p->z, p->w2[i], x_next, h, nullptr, R, D, Hf, Hf, Hf, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
-    if (i + 1 < L) {
-      RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->an[i + 1], x_next, p->xn,
-                                  p->rstd1 + (size_t)(i + 1) * R, R, D, p->eps, p->adapter + (size_t)(i + 1) * A * D, A,
-                                  dt, stream));
-    } else {
-      RUN(fvqa_sumres_rmsnorm_fwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->norm_w, x_next, p->xnf, p->rstdN,
-                                  R, D, p->eps, nullptr, 0, dt, stream));
-    }
+    if (i + 1 < L)
+      RUN(fvqa_rmsnorm_fwd(x_next, p->an[i + 1], p->xn, p->rstd1 + (size_t)(i + 1) * R, R, D, p->eps, dt, stream));
+    else
+      RUN(fvqa_rmsnorm_fwd(x_next, p->norm_w, p->xnf, p->rstdN, R, D, p->eps, dt, stream));
   }
   return FVQA_OK;
 }
@@ -133,6 +131,7 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
   const size_t es = fvqa_dtype_size(dt);
   void* cur = p->dcur;
   void* nxt = p->dnxt;
+  void* t = p->dz;                                     // (R, D) scratch for the GEMM outputs that feed the norm backward
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
   RUN(fvqa_rmsnorm_bwd(dxnf, at(p->xs, (size_t)L * R * D, es), p->norm_w, p->rstdN, nullptr, cur, R, D, dt, stream));
   for (int i = L - 1; i >= 0; --i) {
@@ -146,11 +145,9 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     // dz = cur·W2 never reaches HBM: the SwiGLU backward is this GEMM's epilogue
     RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dab, ab, nullptr, R, Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_SWIGLU_BWD, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
-    int sp = fvqa_gemm_splits(R, D, 2 * Hf, dt);
-    RUN(fvqa_gemm_nt(p->dab, p->w13_t[i], nullptr, nullptr, nullptr, R, D, 2 * Hf, 2 * Hf, 2 * Hf, D, R, dt, dt,
-                     FVQA_EPI_PARTIAL, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
-    RUN(fvqa_sum_rmsnorm_bwd((const float*)p->gemm_ws, sp, (size_t)R * D, h, p->fn[i], p->rstd2 + (size_t)i * R, cur,
-                             p->dh, nullptr, 0, R, D, dt, stream));
+    RUN(fvqa_gemm_nt(p->dab, p->w13_t[i], t, nullptr, nullptr, R, D, 2 * Hf, 2 * Hf, 2 * Hf, D, R, dt, dt,
+                     FVQA_EPI_NONE, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
+    RUN(fvqa_rmsnorm_bwd(t, h, p->fn[i], p->rstd2 + (size_t)i * R, cur, p->dh, R, D, dt, stream));
     RUN(fvqa_gemm_nt(p->dh, p->wo_t[i], p->d_o, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
     if (fused_rope) {
@@ -163,12 +160,14 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
                         stream));
       RUN(fvqa_rope_qk(p->dqkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 1, dt, stream));
     }
-    sp = fvqa_gemm_splits(Ra, D, 3 * D, dt);
-    RUN(fvqa_gemm_nt(p->dqkv, p->wqkv_t[i], nullptr, nullptr, nullptr, Ra, D, 3 * D, 3 * D, 3 * D, D, Ra, dt, dt,
-                     FVQA_EPI_PARTIAL, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
-    RUN(fvqa_sum_rmsnorm_bwd((const float*)p->gemm_ws, sp, (size_t)Ra * D, x, p->an[i], p->rstd1 + (size_t)i * R,
-                             p->dh, nxt, p->d_adapter + (size_t)i * A * D, A, R, D, dt, stream));
-    void* t = cur; cur = nxt; nxt = t;
+    RUN(fvqa_gemm_nt(p->dqkv, p->wqkv_t[i], t, nullptr, nullptr, R, D, 3 * D, 3 * D, 3 * D, D, R, dt, dt,
+                     FVQA_EPI_NONE, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
+    // adapter-query gradient rows (fp32, +=): the A rows under the sequence rows of dqkv hold [0, dK_a, dV_a]
+    RUN(fvqa_gemm_nt(at(p->dqkv, (size_t)R * 3 * D, es), p->wqkv_t[i], nullptr, nullptr,
+                     p->d_adapter + (size_t)i * A * D, A, D, 3 * D, 3 * D, 3 * D, D, 0, dt, dt, FVQA_EPI_NONE, 0,
+                     nullptr, 0, stream));
+    RUN(fvqa_rmsnorm_bwd(t, x, p->an[i], p->rstd1 + (size_t)i * R, p->dh, nxt, R, D, dt, stream));
+    void* sw = cur; cur = nxt; nxt = sw;
   }
   *d_x0 = cur;
   return FVQA_OK;

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL, EPI_SWIGLU_BWD = 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -23,6 +23,8 @@ SIGNATURES = {
     "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "fvqa_gemm_splits": (_i, [_i, _i, _i, _i]),
     "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
+    "fvqa_gemm_sk_workspace": (_sz, []),
+    "fvqa_gemm_sk_describe": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i]),
     "fvqa_gemm_timing_enable": (_i, [_i]),
     "fvqa_gemm_timing_read": (_i, [_i, _p, _p, _p]),
     "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
@@ -65,7 +67,7 @@ class LayerPlan(C.Structure):
         + [("eps", C.c_float), ("reserved_", C.c_int32)]
         + [(n, _pp) for n in ("wqkv", "wo", "w13", "w2", "wqkv_t", "wo_t", "w13_t", "w2_t", "an", "fn", "gate1",
                               "gate2", "dgate1", "dgate2")]
-        + [(n, C.c_void_p) for n in ("adapter", "d_adapter", "norm_w", "xs", "rstd1", "rstd2", "qkv", "o", "lse_a",
+        + [(n, C.c_void_p) for n in ("adapter", "adapter_c", "d_adapter", "norm_w", "xs", "rstd1", "rstd2", "qkv", "o", "lse_a",
                                      "lse_t", "h", "ab", "xn", "hn", "z", "xnf", "rstdN", "cos_t", "sin_t",
                                      "vstart", "dcur", "dnxt", "dz", "dab", "dh", "d_o", "dqkv", "attn_ws")]
         + [("attn_ws_bytes", C.c_size_t), ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t)]

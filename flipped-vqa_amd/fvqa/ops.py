@@ -63,7 +63,9 @@ def gemm_workspace(device, nbytes: int) -> torch.Tensor:
     on the stream: launches are stream-ordered, so sharing is safe)."""
     ws = _GEMM_WS.get(device)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        # zero-filled: the first 4 KiB are the epoch flags of the persistent GEMM (include/fvqa.h), which must
+        # start at zero and are never reset afterwards
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _GEMM_WS[device] = ws
     return ws
 
@@ -72,28 +74,36 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
             tail: Optional[torch.Tensor] = None, m_split: int = 0, variant: int = 0) -> torch.Tensor:
     """out[M,N] = a[M,K] @ b[N,K]^T (+ residual). Rows >= m_split go to `tail` (fp32) when given."""
     _dev(a, b, out, residual, tail)
-    _need(a.dim() == 2 and b.dim() == 2 and out.dim() == 2, "gemm_nt: 2-D operands")
+    _need(a.dim() == 2 and b.dim() == 2, "gemm_nt: 2-D operands")
     M, K = a.shape
     N, K2 = b.shape
     _need(K == K2, f"gemm_nt: K mismatch {K} vs {K2}")
     _need(a.dtype == b.dtype, "gemm_nt: a/b dtype mismatch")
-    _need(out.dtype in (a.dtype, torch.float32), "gemm_nt: out dtype")
-    if tail is None:
-        _need(tuple(out.shape) == (M, N), f"gemm_nt: out shape {tuple(out.shape)} != {(M, N)}")
-        m_split = M
+    if out is None:                                  # every row accumulates into the fp32 tail
+        _need(tail is not None and m_split == 0 and residual is None, "gemm_nt: out=None needs tail and m_split=0")
+        _need(tail.dtype == torch.float32 and tuple(tail.shape) == (M, N), "gemm_nt: tail shape")
+        out_dtype = a.dtype
     else:
-        _need(0 <= m_split <= M, "gemm_nt: m_split")
-        _need(out.shape[0] >= m_split and out.shape[1] == N, "gemm_nt: out too small")
-        _need(tail.dtype == torch.float32 and tuple(tail.shape) == (M - m_split, N), "gemm_nt: tail shape")
+        _need(out.dim() == 2 and out.dtype in (a.dtype, torch.float32), "gemm_nt: out dtype")
+        out_dtype = out.dtype
+        if tail is None:
+            _need(tuple(out.shape) == (M, N), f"gemm_nt: out shape {tuple(out.shape)} != {(M, N)}")
+            m_split = M
+        else:
+            _need(0 <= m_split <= M, "gemm_nt: m_split")
+            _need(out.shape[0] >= m_split and out.shape[1] == N, "gemm_nt: out too small")
+            _need(tail.dtype == torch.float32 and tuple(tail.shape) == (M - m_split, N), "gemm_nt: tail shape")
     epi = EPI_NONE
     if residual is not None:
-        _need(residual.dtype == a.dtype and out.dtype == a.dtype, "gemm_nt: residual dtype")
+        _need(residual.dtype == a.dtype and out_dtype == a.dtype, "gemm_nt: residual dtype")
         _need(residual.shape[1] == N and residual.shape[0] >= min(M, m_split), "gemm_nt: residual shape")
         epi = EPI_RESIDUAL
     lib = _lib.load()
     code = dt_code(a.dtype)
     if variant >= 16:
-        need = (variant - 16) * M * N * 4 if variant > 17 else 0
+        need = ((variant - 16) * M * N * 4 if variant > 17 else 0) + 4096
+    elif variant == 13:
+        need = int(lib.fvqa_gemm_sk_workspace())
     elif variant in (0, 3, 4, 7, 8, 9, 10, 11):
         need = int(lib.fvqa_gemm_workspace(M, N, K, code))
     else:
@@ -104,11 +114,11 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), _ptr(out), _ptr(residual), _ptr(tail), M, N, K, K, K, N, m_split,
-                          code, dt_code(out.dtype), epi, variant, _ptr(ws), ws.numel() if ws is not None else 0,
+                          code, dt_code(out_dtype), epi, variant, _ptr(ws), ws.numel() if ws is not None else 0,
                           _stream())
     if timing is not None:
         e1.record()
-        key = f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_{'res' if epi else 'none'}_{'fix' if need else 'plain'}"
+        key = f"{_DTN[a.dtype]}_{_DTN[out_dtype]}_{'res' if epi else 'none'}_{'fix' if need else 'plain'}"
         timing.append((e0, e1, 2.0 * M * N * K, key))
     _lib.check(rc, "fvqa_gemm_nt")
     return out

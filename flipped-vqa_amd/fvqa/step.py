@@ -86,7 +86,8 @@ class Arena:
         self.lse_t = e(L, n_seq * H * S, dtype=f32)
         self.h = e(L, R, D)
         self.ab = e(L, R, 2 * Hf)
-        self.xn = e(Ra, D)
+        self.xn = e(R, D)
+        self.adapter_c = e(L, A, D)             # storage-dtype cast of the walked layers' adapter prompts
         self.hn = e(R, D)
         self.z = e(R, Hf)
         self.xnf = e(R, D)
@@ -102,7 +103,7 @@ class Arena:
         self.dxnf = e(R, D)
         self.da = e(R, D)
         self.db = e(R, D)
-        self.dz = e(R, Hf)
+        self.dz = e(R, max(Hf, D))              # scratch: GEMM outputs on their way into the norm backward
         self.dab = e(R, 2 * Hf)
         self.dhn = e(R, D)
         self.dh = e(R, D)
@@ -178,6 +179,7 @@ class StepEngine:
         plan.gate1, plan.gate2 = table([g[0] for g in gv]), table([g[1] for g in gv])
         plan.dgate1, plan.dgate2 = table([g[0] for g in gg]), table([g[1] for g in gg])
         plan.adapter = m.adapter_query.weight.data.data_ptr()
+        plan.adapter_c = ar.adapter_c.data_ptr()
         plan.d_adapter = grads.grad_view("adapter_query.weight").data_ptr()
         plan.norm_w = pk.norm.data_ptr()
         for name in ("xs", "rstd1", "rstd2", "qkv", "o", "lse_a", "lse_t", "h", "ab", "xn", "hn", "z", "xnf", "rstdN",
@@ -189,7 +191,8 @@ class StepEngine:
         lib = _lib.load()
         need = int(lib.fvqa_layers_gemm_workspace(C.addressof(plan)))
         if getattr(ar, "plan_ws", None) is None or ar.plan_ws.numel() < need:
-            ar.plan_ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+            # zero-filled: the first 4 KiB are the persistent GEMM's epoch flags (include/fvqa.h)
+            ar.plan_ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=self.device)
         plan.gemm_ws, plan.gemm_ws_bytes = ar.plan_ws.data_ptr(), ar.plan_ws.numel()
         ar._plan, ar._plan_keep, ar._plan_key = plan, keep, key
         return plan
@@ -288,16 +291,14 @@ class StepEngine:
         """The same layer walk as csrc/schedule.hip, one ctypes call per kernel."""
         m, pk = self.model, self.pack
         F, D, A, H, Dh, Hf, L = self.F, self.D, self.A, self.H, self.Dh, self.Hf, self.L
-        R, Ra = ar.R, ar.Ra
+        R = ar.R
         adapter = m.adapter_query.weight.data.view(-1, A, D)     # (adapter_layer, A, D); model.py:304
-        # WO and W2 have N = D outputs (few tiles): their GEMMs leave fp32 split-K partials and the
-        # following "residual add + RMSNorm" kernel sums them (no separate fix-up pass, no extra
-        # round trip of the residual stream through HBM).
+        ops.cast_rows(adapter.reshape(L * A, D), ar.adapter_c.view(L * A, D))
         ops.rmsnorm_fwd(ar.xs[0], pk.an[0], ar.xn, ar.rstd1[0], self.eps, rows=R)
-        ops.cast_rows(adapter[0], ar.xn[R:Ra])                    # later layers: cast rides in the norm kernel
         for i in range(L):
             x = ar.xs[i]
-            ops.gemm_nt(ar.xn, pk.wqkv[i], ar.qkv[i])
+            ops.gemm_nt(ar.xn, pk.wqkv[i], ar.qkv[i][:R])
+            ops.gemm_nt(ar.adapter_c[i], pk.wqkv[i], ar.qkv[i][R:])       # adapter K/V rows (model.py:98-100)
             g1, g2 = m.gate_views(i)
             if ops.attn_rope_fused(self.dtype):             # bf16 MFMA build: q,k stay raw, rotated inside
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F,
@@ -305,16 +306,15 @@ class StepEngine:
             else:
                 ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
-            ws, _ = ops.gemm_nt_partial(ar.o[i], pk.wo[i])
-            ops.sumres_rmsnorm_fwd(ws, x, pk.fn[i], ar.h[i], ar.hn, ar.rstd2[i], self.eps, R)
+            ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)           # h = x + o·Wo^T
+            ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
             ops.gemm_nt(ar.hn, pk.w13[i], ar.ab[i])
             ops.swiglu_fwd(ar.ab[i], ar.z, R, Hf)
-            ws, _ = ops.gemm_nt_partial(ar.z, pk.w2[i])
+            ops.gemm_nt(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i])   # x' = h + z·W2^T
             if i + 1 < L:
-                ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.an[i + 1], ar.xs[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, R,
-                                       tail_src=adapter[i + 1])
+                ops.rmsnorm_fwd(ar.xs[i + 1], pk.an[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, rows=R)
             else:
-                ops.sumres_rmsnorm_fwd(ws, ar.h[i], pk.norm, ar.xs[L], ar.xnf, ar.rstdN, self.eps, R)
+                ops.rmsnorm_fwd(ar.xs[L], pk.norm, ar.xnf, ar.rstdN, self.eps, rows=R)
 
     # ------------------------------------------------------------------ backward
     def backward(self, g_losses: torch.Tensor, grads: "FlatParams"):
@@ -363,14 +363,15 @@ class StepEngine:
     def _layers_bwd_py(self, ar, grads, sv, n_seq, S):
         m, pk = self.model, self.pack
         F, D, A, H, Dh, Hf, L = self.F, self.D, self.A, self.H, self.Dh, self.Hf, self.L
-        R, Ra = ar.R, ar.Ra
+        R = ar.R
         cur, nxt = ar.da, ar.db
+        t = ar.dz.view(-1)[: R * D].view(R, D)
         ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
         g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
         for i in reversed(range(L)):
             ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab)      # dz·SwiGLU' fused in the epilogue
-            ws, _ = ops.gemm_nt_partial(ar.dab, pk.w13_t[i])
-            ops.sum_rmsnorm_bwd(ws, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, R, resid=cur)
+            ops.gemm_nt(ar.dab, pk.w13_t[i], t)
+            ops.rmsnorm_bwd(t, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
             ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)
             g1, g2 = m.gate_views(i)
             dg1, dg2 = grads.gate_grad_views(i)
@@ -381,8 +382,9 @@ class StepEngine:
                 ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1,
                              dg2, ar.attn_ws, n_seq, S, H, Dh, A, F)
                 ops.rope_qk(ar.dqkv, self.cos, self.sin, n_seq, S, H, Dh, inverse=True)
-            ws, _ = ops.gemm_nt_partial(ar.dqkv, pk.wqkv_t[i])
-            ops.sum_rmsnorm_bwd(ws, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, R, resid=ar.dh, tail=g_adapter[i])
+            ops.gemm_nt(ar.dqkv[:R], pk.wqkv_t[i], t)
+            ops.gemm_nt(ar.dqkv[R:], pk.wqkv_t[i], None, tail=g_adapter[i], m_split=0)   # adapter-query grad rows (+=)
+            ops.rmsnorm_bwd(t, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, resid=ar.dh, rows=R)
             cur, nxt = nxt, cur
         return cur
 

@@ -64,10 +64,24 @@ int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* ta
                  int M, int N, int K, int lda, int ldb, int ldc, int m_split,
                  int dtype, int out_dtype, int epilogue, int variant,
                  void* workspace, size_t workspace_bytes, void* stream);
-/* K-splits the 256x256 path picks for a problem (1 = none) and the fp32 partial-sum workspace
- * ([splits][M][N]) it then needs; a too-small/NULL workspace silently falls back to 1 split. */
+/* fvqa_gemm_workspace: bytes of `workspace` that serve whichever kernel variant 0 picks for the problem.
+ * Its FIRST 4096 BYTES are the epoch flags of the work-balanced persistent kernel (csrc/gemm_sk.hip): the caller
+ * zeroes them ONCE after allocating the buffer; no call ever needs them reset. One workspace serves one stream at
+ * a time. fvqa_gemm_splits: K-splits of the older plane path (FVQA_EPI_PARTIAL). */
 int fvqa_gemm_splits(int M, int N, int K, int dtype);
 size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
+/* The persistent kernel (variant 0 for M >= 192, N >= 256, N % 8 == 0, no tail rows; variant 13 forces it): a grid of
+ * at most one workgroup per CU walks whole 256x256 output tiles, or — outputs with few tiles — one K range of a tile
+ * each; a tile shared by several workgroups is reduced inside the launch (fixed order: bitwise repeatable) and stored
+ * once with the epilogue.
+ * fvqa_gemm_sk_workspace: 4096 flag bytes + one 256 KiB fp32 partial-tile slab per workgroup.
+ * fvqa_gemm_sk_describe (host only, no GPU touched): the partition for a problem on n_cu compute units —
+ * plan_out[11] = {tm, tn, wide stages per tile, stages per granule, granules per tile, team size, m groups, teams,
+ * rounds of whole tiles, tiles of the last (split) round, pieces per tile there}; for team >= 0 also its segments, 5 ints each
+ * {tile, k0, k1, pieces n, piece c} (up to max_segs written); returns the team's segment count. */
+size_t fvqa_gemm_sk_workspace(void);
+int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
+                          int32_t* segs_out, int max_segs);
 /* Measurement probe (bench.py roofline; no reference counterpart): while enabled, every launch of the
  * 256x256 GEMM kernel is bracketed by HIP events on ITS launch stream (the kernel only — fix-up
  * passes are outside the pair). fvqa_gemm_timing_read synchronises, returns the number of launches
@@ -237,6 +251,7 @@ typedef struct fvqa_layer_plan {
   float* const* dgate1;      /* (H) fp32, accumulated */
   float* const* dgate2;
   const float* adapter;      /* (L, A, D) fp32 adapter queries of the walked layers */
+  void* adapter_c;           /* (L, A, D) scratch: their storage-dtype cast (written by fvqa_layers_fwd) */
   float* d_adapter;          /* (L, A, D) fp32, accumulated */
   const void* norm_w;        /* final norm weight (D) */
   /* forward arena */
@@ -260,18 +275,19 @@ typedef struct fvqa_layer_plan {
   /* backward scratch */
   void* dcur;                /* (R, D) */
   void* dnxt;                /* (R, D) */
-  void* dz;                  /* (R, Hf) */
+  void* dz;                  /* (R, max(Hf, D)) scratch */
   void* dab;                 /* (R, 2Hf) */
   void* dh;                  /* (R, D) */
   void* d_o;                 /* (R, D) */
   void* dqkv;                /* (Ra, 3D) */
   void* attn_ws;
   size_t attn_ws_bytes;
-  void* gemm_ws;             /* >= fvqa_layers_gemm_workspace(plan) bytes */
+  void* gemm_ws;             /* >= fvqa_layers_gemm_workspace(plan) bytes, 256-byte aligned, first 4096 bytes
+                                zeroed once after allocation (see fvqa_gemm_workspace) */
   size_t gemm_ws_bytes;
 } fvqa_layer_plan;
 
-/* bytes of split-K workspace the GEMMs of one layer (forward and backward) need at most */
+/* bytes of GEMM workspace the projections of one layer (forward and backward) need at most */
 size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* plan);
 /* xs[0] -> ... -> xs[L], xnf = final RMSNorm; saves what the backward needs in the arena */
 int fvqa_layers_fwd(const fvqa_layer_plan* plan, void* stream);

@@ -181,22 +181,6 @@ def test_train_cli_has_reference_flags():
         train.validate_args(a)
 
 
-def test_gemm_decomposition_plans_are_pinned():
-    """Host-only entries of the C ABI (no HIP call behind them): the split-K / tail-round plans the step relies on,
-    pinned through the workspace they ask for ([splits][M][N or tail columns] fp32)."""
-    lib = _lib.load()
-    BF16 = 1
-    ws = lambda M, N, K: int(lib.fvqa_gemm_workspace(M, N, K, BF16))
-    sp = lambda M, N, K: int(lib.fvqa_gemm_splits(M, N, K, BF16))
-    assert sp(1024, 4096, 4096) == 4 and ws(1024, 4096, 4096) == 4 * 1024 * 4096 * 4          # WO: 64 tiles x 4
-    assert sp(1034, 4096, 12288) == 3                                                         # QKV^T: 80 tiles x 3
-    assert sp(1024, 22016, 4096) == 1 and ws(1024, 22016, 4096) == 2 * 1024 * 5632 * 4        # W1|W3: 256 + 88 x 2
-    assert sp(1024, 12288, 4096) == 1 and ws(1034, 12288, 4096) == 0                          # QKV: one round, no plan
-    assert ws(1024, 32000, 4096) == 0                                                         # LM head: 500 tiles, tail too big
-    assert ws(3072, 22016, 4096) == 8 * 3072 * 256 * 4                                        # three streams: 1020 + 12 x 8
-    assert ws(3072, 11008, 4096) == 8 * 3072 * 256 * 4                                        # W2^T under SwiGLU': 504 + 12 x 8
-
-
 def test_bench_launcher_command_and_env():
     """bench.py --gpus N from a plain shell: the child command is the driver's own N>1 form, and a box with fewer
     devices than ranks turns the run into a gloo rehearsal (reference launch: run.sh:20-22 torchrun)."""
@@ -219,3 +203,70 @@ def test_bench_launcher_command_and_env():
     assert env["FVQA_DIST_BACKEND"] == "gloo" and env["FVQA_BENCH_REHEARSAL"] == "1"
     env = bench.launcher_env(2, 0, env={})                     # no device visible: nothing to rehearse on
     assert "FVQA_DIST_BACKEND" not in env
+
+
+def _sk_plan(M, N, K, dtype, n_cu=256):
+    import ctypes as C
+    lib = _lib.load()
+    plan = (C.c_int32 * 11)()
+    lib.fvqa_gemm_sk_describe(M, N, K, dtype, n_cu, C.cast(plan, C.c_void_p), -1, None, 0)
+    keys = ("tm", "tn", "nw_tile", "gran", "gpt", "ts", "mgroups", "n_teams", "full", "rem", "s")
+    p = dict(zip(keys, list(plan)))
+    segs = []
+    for g in range(p["n_teams"]):
+        buf = (C.c_int32 * (5 * 64))()
+        n = lib.fvqa_gemm_sk_describe(M, N, K, dtype, n_cu, None, g, C.cast(buf, C.c_void_p), 64)
+        assert 0 <= n <= 64
+        for i in range(n):
+            tile, k0, k1, pieces, c = list(buf[5 * i:5 * i + 5])
+            segs.append(dict(team=g, order=i, tile=tile, k0=k0, k1=k1, n=pieces, c=c))
+    return p, segs
+
+
+@pytest.mark.parametrize("M,N,K,dtype", [
+    (1024, 12288, 4096, 1), (1024, 4096, 4096, 1), (1024, 22016, 4096, 1), (1024, 4096, 11008, 1),
+    (1024, 11008, 4096, 1), (1024, 4096, 22016, 1), (1024, 4096, 12288, 1), (1024, 32000, 4096, 1),
+    (1024, 4096, 32000, 1), (3072, 12288, 4096, 1), (3072, 4096, 11008, 1), (3072, 22016, 4096, 1),
+    (1950, 4096, 4096, 1), (1950, 11008, 4096, 1), (1536, 15360, 5120, 1), (1536, 5120, 13824, 1),
+    (1536, 27648, 5120, 1), (256, 256, 64, 1), (300, 768, 2112, 0), (1034, 512, 1024, 0), (200, 256, 128, 1),
+    (2048, 2048, 2048, 1), (1024, 4096, 4096, 0), (4096, 4096, 4096, 1), (8192, 8192, 8192, 1), (256, 4096, 4096, 1)])
+def test_persistent_gemm_partition_covers_every_tile_once(M, N, K, dtype):
+    """The (tile, K range) partition of csrc/gemm_sk_plan.h, walked through the host-only C entry: every wide stage of
+    every tile is computed exactly once; a split tile has 2, 4 or 8 pieces in K order held by consecutive teams as
+    their LAST segment after the same number of whole tiles (partners finish together; nobody waits on a workgroup
+    that still has other work to do first)."""
+    for n_cu in (256, 304, 64):
+        p, segs = _sk_plan(M, N, K, dtype, n_cu)
+        assert p["n_teams"] * p["ts"] <= n_cu and p["ts"] * p["mgroups"] >= p["tm"]
+        wide = 64 if dtype == 1 else 32
+        assert p["nw_tile"] == K // wide and p["gpt"] == -(-p["nw_tile"] // p["gran"])
+        tiles = p["mgroups"] * p["tn"]
+        assert p["full"] * p["n_teams"] + p["rem"] == tiles and p["rem"] * p["s"] <= p["n_teams"]
+        by_tile, n_seg = {}, {}
+        for s in segs:
+            assert 0 <= s["tile"] < tiles and 0 <= s["k0"] < s["k1"] <= p["nw_tile"]
+            by_tile.setdefault(s["tile"], []).append(s)
+            n_seg[s["team"]] = n_seg.get(s["team"], 0) + 1
+        assert sorted(by_tile) == list(range(tiles))
+        for t, ss in by_tile.items():
+            ss.sort(key=lambda s: s["k0"])
+            assert ss[0]["k0"] == 0 and ss[-1]["k1"] == p["nw_tile"]
+            assert all(a["k1"] == b["k0"] for a, b in zip(ss, ss[1:]))          # no gap, no overlap
+            n = len(ss)
+            assert n in (1, 2, 4, 8) and n == (p["s"] if t >= p["full"] * p["n_teams"] else 1)
+            for c, s in enumerate(ss):
+                assert s["n"] == n and s["c"] == c
+                if n > 1:
+                    assert s["team"] == ss[0]["team"] + c and s["order"] == p["full"] == n_seg[s["team"]] - 1
+                    assert s["k1"] - s["k0"] > p["gran"]
+
+
+def test_persistent_gemm_plans_of_the_c2_step():
+    """Which partition each projection of the C2 step (7B, M = 1024) gets on 256 CUs: (teams, whole rounds, tiles of the
+    split round, pieces per tile)."""
+    want = {(12288, 4096): (48, 0, 48, 1), (4096, 4096): (64, 0, 16, 4), (22016, 4096): (64, 1, 22, 2),
+            (4096, 11008): (64, 0, 16, 4), (11008, 4096): (43, 0, 43, 1), (4096, 22016): (64, 0, 16, 4),
+            (4096, 12288): (64, 0, 16, 4), (32000, 4096): (64, 1, 61, 1), (4096, 32000): (64, 0, 16, 4)}
+    for (N, K), w in want.items():
+        p, _ = _sk_plan(1024, N, K, 1)
+        assert (p["n_teams"], p["full"], p["rem"], p["s"]) == w and p["ts"] == 4, (N, K, p)

@@ -242,7 +242,7 @@ def main():
         torch.cuda.synchronize()
         gaps = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(128))
         probe_overhead_us = gaps[len(gaps) // 2]
-        epi_name = {0: "none", 1: "residual", 2: "partial", 3: "swiglu_bwd"}
+        epi_name = {0: "none", 1: "residual", 3: "swiglu_bwd"}
         per = {}
         for (us, fl, kind) in rec:
             if us < 0:
@@ -264,7 +264,7 @@ def main():
                 traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
                 tsrc = "profiles/r01_pmc_gemm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, same workload)"
             roof = {"bound": "mfma",
-                    "kernel": "gemm_nt_256 (every launch of every instantiation in the step; mode 6: A2/B3 LDS-DMA rings + wave stagger)",
+                    "kernel": "gemm_sk_256 (every launch of every instantiation in the step: persistent 256x256-tile LDS-DMA ring kernel, split-K reduced in the launch)",
                     "achieved": tot_f / tot_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": tot_f / tot_t / peak, "traffic": traffic, "traffic_source": tsrc,
                     "launches_per_step": n // a.steps, "avg_launch_us": tot_t / n * 1e6,

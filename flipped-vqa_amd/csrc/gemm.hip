@@ -14,6 +14,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles that
 // walk M fastest: the 8..24 row-tiles sharing one weight panel hit that panel in one L2.
 #include "common.h"
+#include "gemm_skinny.h"
 
 namespace {
 
@@ -202,54 +203,14 @@ int launch_128(const void* A, const void* B, void* C, const void* R, float* tail
   return FVQA_OK;
 }
 
-// ---- skinny GEMM for the decode shape (M <= 16 rows: one new token per sequence; generation path) -----------
-// HBM-bound on the weight stream, so the layout is chosen for bytes in flight, not for MFMA rate: one 512-thread
-// workgroup per strip of 16 output columns, its 8 waves split K eight ways (each keeps 8 k-steps = 16 KiB of
-// weight + activation fragments in flight from global memory, no LDS staging), the 8 partial 16x16 blocks meet
-// in LDS. The MFMA is fed the weight strip as its row operand, so a lane ends up with 4 consecutive columns of
-// one row (the same transposed-block trick as the 256x256 epilogue).
-// EPI: none / residual (C = acc + R) / FVQA_EPI_SKINNY_ACC (fp32 C += acc: gradient rows summed into a grad buffer).
-constexpr int FVQA_EPI_SKINNY_ACC = 100;
+// ---- decode-shape GEMM (M <= 16 rows: one new token per sequence; adapter rows): one strip of 16 output columns per
+// workgroup (gemm_skinny.h)
 template <typename TO, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_skinny(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       TO* __restrict__ C, const bf16_t* __restrict__ R, int M, int N,
                                                       int K, int lda, int ldb, int ldc) {
   __shared__ float part[8][16][20];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int li = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-  const int kw = K / 8;                                    // this wave's K range (K % 256 == 0)
-  int bn = n0 + li; bn = bn < N ? bn : N - 1;
-  int am = li < M ? li : M - 1;
-  const bf16_t* bp = B + (size_t)bn * ldb + (size_t)w * kw + 8 * g;
-  const bf16_t* ap = A + (size_t)am * lda + (size_t)w * kw + 8 * g;
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < kw; k0 += 256) {
-    uint4 bf[8], af[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = k0 + 32 * u;
-      const bool in = k < kw;
-      bf[u] = in ? *reinterpret_cast<const uint4*>(bp + k) : make_uint4(0, 0, 0, 0);
-      af[u] = in ? *reinterpret_cast<const uint4*>(ap + k) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) Mma<bf16_t>::run(bf[u], af[u], acc);     // D[n = 4g+r][m = li]
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) part[w][li][4 * g + r] = acc[r];           // [wave][m][n]
-  __syncthreads();
-  if (threadIdx.x < 256) {
-    const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
-    if (m < M && n0 + n < N) {
-      float v = 0.f;
-#pragma unroll
-      for (int ww = 0; ww < 8; ++ww) v += part[ww][m][n];
-      if (EPI == FVQA_EPI_RESIDUAL) v += to_f32<bf16_t>(R[(size_t)m * ldc + n0 + n]);
-      if (EPI == FVQA_EPI_SKINNY_ACC) v += to_f32<TO>(C[(size_t)m * ldc + n0 + n]);
-      C[(size_t)m * ldc + n0 + n] = from_f32<TO>(v);
-    }
-  }
+  skinny_strip<TO, EPI>(A, B, C, R, M, N, K, lda, ldb, ldc, blockIdx.x * 16, part);
 }
 
 template <typename TO>
@@ -271,32 +232,29 @@ int launch_skinny(const void* A, const void* B, void* C, const void* R, int M, i
 
 }  // namespace
 
-#define FVQA_GEMM256_DEFAULT_MODE 6
 extern "C" size_t fvqa_gemm_sk_workspace(void);
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
-                      int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st);
-int fvqa_gemm_nt_256_impl(const void* A, const void* B, void* C, const void* R, float* tail, void* ws,
-                          size_t ws_bytes, int M, int N, int K, int lda, int ldb, int ldc, int m_split, int dtype,
-                          int out_dtype, int epilogue, int force_splits, int mode, hipStream_t st);
+                      int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
+                      const fvqa_sk_rider* rider, int* rode);
 
-// variant: 0 = auto (256x256 ring kernel with automatic split-K when the problem is large enough,
-// else the 128x128 kernel); 1 = 128x128 register-staged; 2 = 128x128 LDS-DMA; 3 = 256x256 default
-// loop; 4 = 256x256 plain 64-byte-row ring loop;
-// 7 = 256x256 wide-row (128-byte) two-stage ring; 8 = wide-row asymmetric rings (A x2, B x3, role-split DMA); 9 = the same with waves 4-7 staggered by half a stage (the default loop, tile width chosen per problem);
-// 10 / 11 = the default loop with the tile forced 192 / 256 columns wide; 12 = the skinny (M <= 16) decode kernel;
-// 13 = the work-balanced persistent kernel (gemm_sk.hip; what variant 0 picks for large problems);
-// 16+s = 256x256 default loop with exactly s K-splits (tests / tuning).
+extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
+  (void)K; (void)dtype;
+  return (M >= 192 && N >= 256) ? fvqa_gemm_sk_workspace() : 0;
+}
+
+// variant: 0 = auto — the persistent 256-row kernel (gemm_sk.hip) for large problems it can store in whole 16-byte
+// chunks, the decode-shape kernel for M <= 16 (bf16), else the 128x128 kernel; 1 = 128x128 register-staged;
+// 2 = 128x128 LDS-DMA; 12 = the decode-shape (M <= 16) kernel; 13 = the persistent kernel (tests, tuning).
 extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail, int M, int N,
                             int K, int lda, int ldb, int ldc, int m_split, int dtype, int out_dtype, int epilogue,
                             int variant, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!A || !B || (!C && epilogue != FVQA_EPI_PARTIAL && !(tail && m_split == 0))) return FVQA_EINVAL;
+  if (!A || !B || (!C && !(tail && m_split == 0))) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype) || !fvqa_dtype_ok(out_dtype)) return FVQA_EINVAL;
-  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_PARTIAL &&
-      epilogue != FVQA_EPI_SWIGLU_BWD)
-    return FVQA_EINVAL;
+  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_SWIGLU_BWD) return FVQA_EINVAL;
   if ((epilogue == FVQA_EPI_RESIDUAL || epilogue == FVQA_EPI_SWIGLU_BWD) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
   if (epilogue == FVQA_EPI_SWIGLU_BWD && (tail || ldc != 2 * N)) return FVQA_EINVAL;
   if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 12 && variant != 13) return FVQA_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return FVQA_ESHAPE;
   const int ke = dtype == FVQA_BF16 ? 64 : 32;
   if (K % ke) return FVQA_ESHAPE;
@@ -305,29 +263,14 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
     return FVQA_EALIGN;
   if (lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
-  // the work-balanced persistent kernel (gemm_sk.hip) takes every large problem whose output rows it can store in
-  // whole 16-byte chunks; the first 4 KiB of the workspace are its epoch flags (zeroed once by the caller), so the
-  // older split-K paths below get the workspace past them
-  const size_t sync_bytes = 4096;
-  const bool sk_ok = epilogue != FVQA_EPI_PARTIAL && tail == nullptr && (N & 7) == 0 && (ldc & 7) == 0 && C &&
+  const bool sk_ok = tail == nullptr && (N & 7) == 0 && (ldc & 7) == 0 && C &&
                      (((uintptr_t)C | (uintptr_t)R) & 15) == 0 && workspace != nullptr &&
                      ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace();
   if (variant == 13 && !sk_ok) return FVQA_EALIGN;
-  if (variant == 13 || (variant == 0 && sk_ok && M >= 192 && N >= 256))
-    return fvqa_gemm_sk_impl(A, B, C, R, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, dtype, out_dtype, epilogue, st);
-  if (workspace != nullptr && workspace_bytes > sync_bytes) {
-    workspace = (char*)workspace + sync_bytes;
-    workspace_bytes -= sync_bytes;
-  } else {
-    workspace = nullptr;
-    workspace_bytes = 0;
-  }
-  const bool big = epilogue == FVQA_EPI_PARTIAL || epilogue == FVQA_EPI_SWIGLU_BWD || (variant >= 3 && variant <= 11 && variant != 5 && variant != 6) || variant >= 16 || (variant == 0 && M >= 192 && N >= 256);
-  if (big) {
-    const int mode = variant == 4 ? 0 : variant == 7 ? 2 : variant == 8 ? 3 : variant == 9 ? 6 : variant == 10 ? 63 : variant == 11 ? 61 : FVQA_GEMM256_DEFAULT_MODE;
-    return fvqa_gemm_nt_256_impl(A, B, C, R, tail, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, m_split, dtype,
-                                 out_dtype, epilogue, variant >= 16 ? variant - 16 : 0, mode, st);
-  }
+  if (variant == 13 || (variant == 0 && sk_ok && ((M >= 192 && N >= 256) || epilogue == FVQA_EPI_SWIGLU_BWD)))
+    return fvqa_gemm_sk_impl(A, B, C, R, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, dtype, out_dtype, epilogue, st,
+                             nullptr, nullptr);
+  if (epilogue == FVQA_EPI_SWIGLU_BWD) return FVQA_EALIGN;    // that epilogue lives in the persistent kernel only
   // every row goes to the fp32 tail (m_split == 0): the decode-shape kernel accumulates straight into it
   if (dtype == FVQA_BF16 && M <= 16 && (K % 256) == 0 && tail != nullptr && m_split == 0 && epilogue == FVQA_EPI_NONE &&
       (variant == 0 || variant == 12))
@@ -349,4 +292,41 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
   }
   return glds ? launch_128<float, float, true>(A, B, C, R, tail, M, N, K, lda, ldb, ldc, m_split, epilogue, st)
               : launch_128<float, float, false>(A, B, C, R, tail, M, N, K, lda, ldb, ldc, m_split, epilogue, st);
+}
+
+// C = A·B^T (+ epilogue) as fvqa_gemm_nt variant 0 computes it, and the small product `rider` — on the CUs the main
+// problem leaves idle when the persistent kernel runs it with >= 16 of them to spare, else as its own launch right
+// after. Same arithmetic either way (gemm_skinny.h), so results do not depend on where the rider ran.
+extern "C" int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                                  int ldb, int ldc, int dtype, int out_dtype, int epilogue,
+                                  const fvqa_sk_rider* rider, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!rider || !rider->A || !rider->B || !rider->C || rider->M <= 0 || rider->N <= 0 || rider->K <= 0) return FVQA_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const bool sk_ok = A && B && C && fvqa_dtype_ok(dtype) && (N & 7) == 0 && (ldc & 7) == 0 &&
+                     (((uintptr_t)C | (uintptr_t)R) & 15) == 0 && workspace != nullptr &&
+                     ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace() &&
+                     ((M >= 192 && N >= 256) || epilogue == FVQA_EPI_SWIGLU_BWD);
+  int rode = 0;
+  int rc;
+  if (sk_ok) {
+    if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_SWIGLU_BWD) return FVQA_EINVAL;
+    if ((epilogue == FVQA_EPI_RESIDUAL || epilogue == FVQA_EPI_SWIGLU_BWD) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
+    if (epilogue == FVQA_EPI_SWIGLU_BWD && ldc != 2 * N) return FVQA_EINVAL;
+    if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
+    const int ke = dtype == FVQA_BF16 ? 64 : 32;
+    const size_t es = fvqa_dtype_size(dtype);
+    if (M <= 0 || N <= 0 || K <= 0 || (K % ke) || lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
+    if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((size_t)lda * es & 15) || ((size_t)ldb * es & 15)) return FVQA_EALIGN;
+    rc = fvqa_gemm_sk_impl(A, B, C, R, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, dtype, out_dtype, epilogue, st,
+                           rider, &rode);
+  } else {
+    rc = fvqa_gemm_nt(A, B, C, R, nullptr, M, N, K, lda, ldb, ldc, M, dtype, out_dtype, epilogue, 0, workspace,
+                      workspace_bytes, stream);
+  }
+  if (rc || rode) return rc;
+  if (rider->accumulate_f32)
+    return fvqa_gemm_nt(rider->A, rider->B, nullptr, nullptr, (float*)rider->C, rider->M, rider->N, rider->K, rider->lda,
+                        rider->ldb, rider->ldc, 0, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+  return fvqa_gemm_nt(rider->A, rider->B, rider->C, nullptr, nullptr, rider->M, rider->N, rider->K, rider->lda, rider->ldb,
+                      rider->ldc, rider->M, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
 }

@@ -21,6 +21,7 @@
 // is resident. A spin that runs out (~1 s) raises the error word of the workspace and lets the grid drain.
 #include "gemm256_loop.h"
 #include "gemm_sk_plan.h"
+#include "gemm_skinny.h"
 #include "probe.h"
 #include <atomic>
 
@@ -31,12 +32,24 @@ typedef unsigned long long u64;
 constexpr int SLAB_FLOATS = 8 * 32 * 256;            // 8 waves x 32 blocks x (64 lanes x 4) = 256 KiB
 constexpr size_t SYNC_BYTES = 4096;                   // u64 words: [0] error, [1 + workgroup] epoch flags (<= 511)
 
+// A second, independent product of at most 16 rows (bf16) that rides on the CUs the main problem leaves idle:
+// C2 = A2 · B2^T, strip by strip with the decode-shape routine of gemm_skinny.h (HBM-bound on B2's stream). The step
+// uses it for the 10 adapter rows: their K/V projections beside the QKV GEMM (192 of 256 CUs busy) and their
+// gradient rows beside the W2^T GEMM (172 busy) — as separate launches they cost 21 us each, 1.4 ms per step.
+struct SkRider {
+  const void* A; const void* B; void* C;
+  int M, N, K, lda, ldb, ldc;
+  int acc;               // 0: C (storage dtype) = product; 1: C (fp32) += product
+  int n_wg;              // workgroups appended to the grid for it (0: no rider)
+};
+
 struct SkArgs {
   const void* A; const void* B; void* C; const void* R;
   float* slabs; u64* sync; u64* stamps;
   int M, N, K, lda, ldb, ldc;
   u64 epoch;
   fvqa_sk_plan plan;
+  SkRider rider;
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nwg) {     // consecutive work ids share an XCD (bijective)
@@ -264,7 +277,24 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
   const fvqa_sk_plan& P = a.plan;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wid = xcd_chunk(blockIdx.x, gridDim.x);
+  const int n_main = P.n_teams * P.ts;
+  if ((int)blockIdx.x >= n_main) {                        // rider workgroups (spread over the XCDs by the dispatcher)
+    if constexpr (sizeof(T) == 2) {
+      const SkRider& r = a.rider;
+      float(*part)[16][20] = reinterpret_cast<float(*)[16][20]>(smem);
+      for (int strip = (int)blockIdx.x - n_main; strip * 16 < r.N; strip += r.n_wg) {
+        if (r.acc)
+          skinny_strip<float, FVQA_EPI_SKINNY_ACC>((const bf16_t*)r.A, (const bf16_t*)r.B, (float*)r.C, nullptr, r.M, r.N,
+                                                   r.K, r.lda, r.ldb, r.ldc, strip * 16, part);
+        else
+          skinny_strip<bf16_t, FVQA_EPI_NONE>((const bf16_t*)r.A, (const bf16_t*)r.B, (bf16_t*)r.C, nullptr, r.M, r.N,
+                                              r.K, r.lda, r.ldb, r.ldc, strip * 16, part);
+        __syncthreads();                                  // `part` is rewritten by the next strip
+      }
+    }
+    return;
+  }
+  const int wid = xcd_chunk(blockIdx.x, n_main);
   const int g = wid / P.ts, jm = wid - g * P.ts;
   SK_STAMP(0);
   fvqa_sk_seg s;
@@ -315,7 +345,7 @@ int launch_sk(const SkArgs& a, hipStream_t st) {
   }
   {
     FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (a.plan.s > 1 ? 16 : 0) | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
-    hipLaunchKernelGGL(k, dim3(a.plan.n_teams * a.plan.ts), dim3(512), RING_BYTES, st, a);
+    hipLaunchKernelGGL(k, dim3(a.plan.n_teams * a.plan.ts + a.rider.n_wg), dim3(512), RING_BYTES, st, a);
   }
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
@@ -366,8 +396,12 @@ extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, i
 
 // C[M,N] = A[M,K] x B[N,K]^T with the epilogue applied once per finished tile. `ws`: fvqa_gemm_sk_workspace()
 // bytes whose first 4096 were zeroed once by the caller after allocation (epoch flags; never reset afterwards).
+// rider (may be NULL): see SkRider; *rode <- 1 when it was put on this launch's idle CUs (>= 16 of them, bf16), else 0
+// and the caller launches it on its own.
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
-                      int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st) {
+                      int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
+                      const fvqa_sk_rider* rider, int* rode) {
+  if (rode) *rode = 0;
   if (!ws || ws_bytes < fvqa_gemm_sk_workspace() || ((uintptr_t)ws & 255)) return FVQA_EALIGN;
   const int n_cu = cu_count();
   SkArgs a;
@@ -379,6 +413,15 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   a.plan = fvqa_sk_make_plan(M, N, K, dtype == FVQA_BF16 ? 64 : 32, n_cu < 256 ? n_cu : 256);
   if (a.plan.n_teams * a.plan.ts > 256 || a.plan.n_teams * a.plan.ts > n_cu) return FVQA_ESHAPE;
   a.epoch = g_epoch.fetch_add(1) + 1;
+  a.rider = SkRider{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int idle = (n_cu < 256 ? n_cu : 256) - a.plan.n_teams * a.plan.ts;
+  if (rider && dtype == FVQA_BF16 && idle >= 16 && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 &&
+      rider->N > 0 && rider->A && rider->B && rider->C) {
+    const int strips = (rider->N + 15) / 16;
+    a.rider = SkRider{rider->A, rider->B, rider->C, rider->M, rider->N, rider->K, rider->lda, rider->ldb, rider->ldc,
+                      rider->accumulate_f32, idle < strips ? idle : strips};
+    if (rode) *rode = 1;
+  }
 #define SK(T, TO)                                                                             \
   switch (epilogue) {                                                                         \
     case FVQA_EPI_NONE: return launch_sk<T, TO, FVQA_EPI_NONE>(a, st);                        \

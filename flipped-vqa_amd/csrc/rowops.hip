@@ -10,8 +10,7 @@ constexpr int ROWS_PER_BLOCK = 4;   // 4 waves per 256-thread workgroup
 // ---- RMSNorm (reference llama/model.py:37-42) ---------------------------------------------
 // One 256-thread workgroup per row; a thread owns 8-element chunks c = 8*tid + 2048*k, loaded once
 // with 16-byte (bf16) / 2x16-byte (fp32) vector loads and kept in registers across the reduction
-// (single pass over HBM). The *_sum variants take the row as split-K partial sums of the producing
-// GEMM (fp32 [splits][rows_total][dim]) — the GEMM fix-up pass is fused into the norm.
+// (single pass over HBM).
 constexpr int NORM_MAXK = 4;          // dim <= 8192
 
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
@@ -39,52 +38,19 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
   t.w = (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16);
   *reinterpret_cast<uint4*>(p) = t;
 }
-// row value = sum of split-K partials (fp32)
-__device__ __forceinline__ void load8_sum(const float* ws, int splits, size_t plane, float (&v)[8]) {
-  load8<float>(ws, v);
-  for (int s = 1; s < splits; ++s) {
-    float u[8];
-    load8<float>(ws + s * plane, u);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += u[i];
-  }
-}
-
-// SUM: x := round_T(resid + sum_s ws[s]) is also stored to `h` (the residual stream)
-template <typename T, bool SUM>
-__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, const float* __restrict__ ws,
-                                                     int splits, size_t plane, const T* __restrict__ resid,
-                                                     const T* __restrict__ w, T* __restrict__ h,
-                                                     T* __restrict__ y, float* __restrict__ rstd, int dim,
-                                                     float eps, int rows, const float* __restrict__ cast_src) {
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, const T* __restrict__ w,
+                                                     T* __restrict__ y, float* __restrict__ rstd, int dim, float eps) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)row * dim;
-  if (row >= rows) {        // rows riding under the normalised ones: y[row] = storage-dtype cast of fp32 cast_src
-    const float* src = cast_src + (size_t)(row - rows) * dim;      // (next layer's adapter rows, llama/model.py:339)
-    for (int c = tid * 8; c < dim; c += 2048) {
-      float v[8];
-      load8<float>(src + c, v);
-      store8<T>(y + base + c, v);
-    }
-    return;
-  }
   float xv[NORM_MAXK][8];
   float ss = 0.f;
 #pragma unroll
   for (int k = 0; k < NORM_MAXK; ++k) {
     const int c = tid * 8 + k * 2048;
     if (c < dim) {
-      if (SUM) {
-        float r[8];
-        load8_sum(ws + base + c, splits, plane, xv[k]);
-        load8<T>(resid + base + c, r);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) xv[k][i] = round_to<T>(xv[k][i] + r[i]);
-        store8<T>(h + base + c, xv[k]);
-      } else {
-        load8<T>(x + base + c, xv[k]);
-      }
+      load8<T>(x + base + c, xv[k]);
 #pragma unroll
       for (int i = 0; i < 8; ++i) ss += xv[k][i] * xv[k][i];
     }
@@ -105,28 +71,13 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_k(const T* __restrict__ x, co
   }
 }
 
-// SUM: the upstream gradient g is the sum of split-K partials (kept in fp32, never rounded)
-template <typename T, bool SUM>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ g, const float* __restrict__ ws,
-                                                     int splits, size_t plane, const T* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ g, const T* __restrict__ x,
                                                      const T* __restrict__ w, const float* __restrict__ rstd,
-                                                     const T* __restrict__ resid, T* __restrict__ dx, int dim,
-                                                     int rows, float* __restrict__ tail) {
+                                                     const T* __restrict__ resid, T* __restrict__ dx, int dim) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   const size_t base = (size_t)row * dim;
-  if (row >= rows) {        // tail[r, :] += sum_s ws[s][rows + r, :] (fp32 adapter-gradient rows under the split-K GEMM)
-    float* t = tail + (size_t)(row - rows) * dim;
-    for (int c = tid * 8; c < dim; c += 2048) {
-      float v[8], u[8];
-      load8_sum(ws + base + c, splits, plane, v);
-      load8<float>(t + c, u);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) u[i] += v[i];
-      store8<float>(t + c, u);
-    }
-    return;
-  }
   float xv[NORM_MAXK][8], gw[NORM_MAXK][8];
   float dot = 0.f;
 #pragma unroll
@@ -135,8 +86,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_k(const T* __restrict__ g, co
     if (c < dim) {
       float wv[8];
       load8<T>(x + base + c, xv[k]);
-      if (SUM) load8_sum(ws + base + c, splits, plane, gw[k]);
-      else load8<T>(g + base + c, gw[k]);
+      load8<T>(g + base + c, gw[k]);
       load8<T>(w + c, wv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -319,22 +269,8 @@ extern "C" int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rs
   if (!x || !w || !y) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
   if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T, false>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
-                                       (const T*)x, nullptr, 0, 0, nullptr, (const T*)w, nullptr, (T*)y, rstd, dim,
-                                       eps, rows, nullptr));
-  FVQA_CHECK_LAUNCH();
-  return FVQA_OK;
-}
-
-extern "C" int fvqa_sumres_rmsnorm_fwd(const float* ws, int splits, size_t plane, const void* resid, const void* w,
-                                       void* h, void* y, float* rstd, int rows, int dim, float eps,
-                                       const float* tail_src, int tail_rows, int dtype, void* stream) {
-  if (!ws || !resid || !w || !h || !y) return FVQA_EINVAL;
-  if (!fvqa_dtype_ok(dtype) || splits < 1 || (tail_rows > 0 && !tail_src)) return FVQA_EINVAL;
-  if (!norm_dims_ok(rows, dim) || tail_rows < 0) return FVQA_ESHAPE;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T, true>), dim3(rows + tail_rows), dim3(256), 0,
-                                       (hipStream_t)stream, nullptr, ws, splits, plane, (const T*)resid, (const T*)w,
-                                       (T*)h, (T*)y, rstd, dim, eps, rows, tail_src));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_k<T>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)x, (const T*)w, (T*)y, rstd, dim, eps));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
@@ -344,22 +280,8 @@ extern "C" int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, con
   if (!g || !x || !w || !rstd || !dx) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
   if (!norm_dims_ok(rows, dim)) return FVQA_ESHAPE;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T, false>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
-                                       (const T*)g, nullptr, 0, 0, (const T*)x, (const T*)w, rstd, (const T*)resid,
-                                       (T*)dx, dim, rows, nullptr));
-  FVQA_CHECK_LAUNCH();
-  return FVQA_OK;
-}
-
-extern "C" int fvqa_sum_rmsnorm_bwd(const float* ws, int splits, size_t plane, const void* x, const void* w,
-                                    const float* rstd, const void* resid, void* dx, float* tail, int tail_rows,
-                                    int rows, int dim, int dtype, void* stream) {
-  if (!ws || !x || !w || !rstd || !dx) return FVQA_EINVAL;
-  if (!fvqa_dtype_ok(dtype) || splits < 1 || (tail_rows > 0 && !tail)) return FVQA_EINVAL;
-  if (!norm_dims_ok(rows, dim) || tail_rows < 0) return FVQA_ESHAPE;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T, true>), dim3(rows + tail_rows), dim3(256), 0,
-                                       (hipStream_t)stream, nullptr, ws, splits, plane, (const T*)x, (const T*)w, rstd,
-                                       (const T*)resid, (T*)dx, dim, rows, tail));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_k<T>), dim3(rows), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)g, (const T*)x, (const T*)w, rstd, (const T*)resid, (T*)dx, dim));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }

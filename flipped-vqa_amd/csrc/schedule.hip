@@ -17,6 +17,7 @@
 #include "common.h"
 
 extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p);
+extern "C" size_t fvqa_gemm_sk_workspace(void);
 
 namespace {
 
@@ -50,6 +51,16 @@ int check_plan(const fvqa_layer_plan* p) {
   return FVQA_OK;
 }
 
+// adapter_query.grad rows of walked layer i (fp32, +=): the A rows under the sequence rows of dqkv hold
+// [0, dK_a, dV_a] (summed over the batch by the attention backward), so only the K/V column blocks take part:
+// d_adapter[i] += dqkv[R:, D:3D] · Wqkv^T[:, D:3D]^T
+fvqa_sk_rider adapter_grad_rider(const fvqa_layer_plan* p, int i) {
+  const int D = p->dim, A = p->adapter_len, R = p->n_seq * p->seq_len;
+  const size_t es = fvqa_dtype_size(p->dtype);
+  return fvqa_sk_rider{at(p->dqkv, (size_t)R * 3 * D + D, es), at(p->wqkv_t[i], (size_t)D, es),
+                       p->d_adapter + (size_t)i * A * D, A, D, 2 * D, 3 * D, 3 * D, D, 1};
+}
+
 }  // namespace
 
 extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p) {
@@ -61,7 +72,7 @@ extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p) {
   upd(fvqa_gemm_workspace(R, D, D, dt));            // WO, WO^T
   upd(fvqa_gemm_workspace(R, 2 * Hf, D, dt));       // W1|W3
   upd(fvqa_gemm_workspace(R, D, Hf, dt));           // W2
-  upd(fvqa_gemm_workspace(R, Hf, D, dt));           // W2^T
+  upd(fvqa_gemm_sk_workspace());                    // W2^T: its SwiGLU' epilogue lives in the persistent kernel only
   upd(fvqa_gemm_workspace(R, D, 2 * Hf, dt));       // W1|W3^T
   upd(fvqa_gemm_workspace(R, D, 3 * D, dt));        // QKV^T
   return need;
@@ -87,11 +98,12 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
     float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
     float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
-    RUN(fvqa_gemm_nt(p->xn, p->wqkv[i], qkv, nullptr, nullptr, R, 3 * D, D, D, D, 3 * D, R, dt, dt, FVQA_EPI_NONE, 0,
-                     p->gemm_ws, p->gemm_ws_bytes, stream));
-    // adapter rows ride under the sequence rows of qkv: their projections stream the (cache-warm) weights once more
-    RUN(fvqa_gemm_nt(at(p->adapter_c, (size_t)i * A * D, es), p->wqkv[i], at(qkv, (size_t)R * 3 * D, es), nullptr,
-                     nullptr, A, 3 * D, D, D, D, 3 * D, A, dt, dt, FVQA_EPI_NONE, 0, nullptr, 0, stream));
+    // the A adapter rows under the sequence rows of qkv get their K and V projections (model.py:98-100; their q block
+    // is never read) on the CUs the QKV GEMM leaves idle
+    const fvqa_sk_rider kv = {at(p->adapter_c, (size_t)i * A * D, es), at(p->wqkv[i], (size_t)D * D, es),
+                              at(qkv, (size_t)R * 3 * D + D, es), A, 2 * D, D, D, D, 3 * D, 0};
+    RUN(fvqa_gemm_nt_rider(p->xn, p->wqkv[i], qkv, nullptr, R, 3 * D, D, D, D, 3 * D, dt, dt, FVQA_EPI_NONE, &kv,
+                           p->gemm_ws, p->gemm_ws_bytes, stream));
     if (fused_rope) {                                  // bf16 MFMA build: q,k stay raw and are rotated inside
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t, n_seq, S, H, Dh,
                         A, p->max_feats, dt, stream));
@@ -142,9 +154,16 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     const void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
     const float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
     const float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
-    // dz = cur·W2 never reaches HBM: the SwiGLU backward is this GEMM's epilogue
-    RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dab, ab, nullptr, R, Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_SWIGLU_BWD, 0,
-                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    // dz = cur·W2 never reaches HBM: the SwiGLU backward is this GEMM's epilogue. On its idle CUs: the adapter-query
+    // gradient rows of the layer walked just before (dqkv still holds that layer's [0, dK_a, dV_a] rows)
+    if (i + 1 < L) {
+      const fvqa_sk_rider ga = adapter_grad_rider(p, i + 1);
+      RUN(fvqa_gemm_nt_rider(cur, p->w2_t[i], p->dab, ab, R, Hf, D, D, D, 2 * Hf, dt, dt, FVQA_EPI_SWIGLU_BWD, &ga,
+                             p->gemm_ws, p->gemm_ws_bytes, stream));
+    } else {
+      RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dab, ab, nullptr, R, Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_SWIGLU_BWD, 0,
+                       p->gemm_ws, p->gemm_ws_bytes, stream));
+    }
     RUN(fvqa_gemm_nt(p->dab, p->w13_t[i], t, nullptr, nullptr, R, D, 2 * Hf, 2 * Hf, 2 * Hf, D, R, dt, dt,
                      FVQA_EPI_NONE, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
     RUN(fvqa_rmsnorm_bwd(t, h, p->fn[i], p->rstd2 + (size_t)i * R, cur, p->dh, R, D, dt, stream));
@@ -162,12 +181,13 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     }
     RUN(fvqa_gemm_nt(p->dqkv, p->wqkv_t[i], t, nullptr, nullptr, R, D, 3 * D, 3 * D, 3 * D, D, R, dt, dt,
                      FVQA_EPI_NONE, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
-    // adapter-query gradient rows (fp32, +=): the A rows under the sequence rows of dqkv hold [0, dK_a, dV_a]
-    RUN(fvqa_gemm_nt(at(p->dqkv, (size_t)R * 3 * D, es), p->wqkv_t[i], nullptr, nullptr,
-                     p->d_adapter + (size_t)i * A * D, A, D, 3 * D, 3 * D, 3 * D, D, 0, dt, dt, FVQA_EPI_NONE, 0,
-                     nullptr, 0, stream));
     RUN(fvqa_rmsnorm_bwd(t, x, p->an[i], p->rstd1 + (size_t)i * R, p->dh, nxt, R, D, dt, stream));
     void* sw = cur; cur = nxt; nxt = sw;
+  }
+  {                                                    // layer 0's adapter-query gradient rows: nothing left to ride on
+    const fvqa_sk_rider ga = adapter_grad_rider(p, 0);
+    RUN(fvqa_gemm_nt(ga.A, ga.B, nullptr, nullptr, (float*)ga.C, ga.M, ga.N, ga.K, ga.lda, ga.ldb, ga.ldc, 0, dt, dt,
+                     FVQA_EPI_NONE, 0, nullptr, 0, stream));
   }
   *d_x0 = cur;
   return FVQA_OK;

@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_RESIDUAL, EPI_PARTIAL, EPI_SWIGLU_BWD = 0, 1, 2, 3
+EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD = 0, 1, 3
 ABI_VERSION = 8
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
@@ -21,16 +21,14 @@ SIGNATURES = {
     "fvqa_version": (_i, []),
     "fvqa_arch": (C.c_char_p, []),
     "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
-    "fvqa_gemm_splits": (_i, [_i, _i, _i, _i]),
     "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
     "fvqa_gemm_sk_workspace": (_sz, []),
+    "fvqa_gemm_nt_rider": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "fvqa_gemm_sk_describe": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i]),
     "fvqa_gemm_timing_enable": (_i, [_i]),
     "fvqa_gemm_timing_read": (_i, [_i, _p, _p, _p]),
     "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
     "fvqa_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "fvqa_sumres_rmsnorm_fwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _i, _i, _f, _p, _i, _i, _p]),
-    "fvqa_sum_rmsnorm_bwd": (_i, [_p, _i, _sz, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fvqa_rope_qk": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_swiglu_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "fvqa_swiglu_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
@@ -57,6 +55,12 @@ SIGNATURES = {
 }
 
 _pp = C.POINTER(C.c_void_p)
+
+
+class SkRider(C.Structure):
+    """Mirror of `fvqa_sk_rider` (include/fvqa.h)."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "accumulate_f32")]
 
 
 class LayerPlan(C.Structure):

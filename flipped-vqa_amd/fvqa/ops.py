@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_NONE, EPI_PARTIAL, EPI_RESIDUAL, EPI_SWIGLU_BWD, F32
+from ._lib import BF16, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, F32
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _DTN = {torch.float32: "f32", torch.bfloat16: "bf16"}
@@ -31,14 +31,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _dev(*ts):
+def _dev(*ts, rows_strided: bool = False):
+    """rows_strided: 2-D views with unit inner stride are accepted (column blocks of wider matrices)."""
     dev = None
     for t in ts:
         if t is None:
             continue
         if not t.is_cuda:
             raise ValueError("fvqa ops need device tensors (no CPU fallback exists)")
-        if not t.is_contiguous():
+        if rows_strided:
+            if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+                raise ValueError("fvqa GEMM operands must be 2-D with unit inner stride")
+        elif not t.is_contiguous():
             raise ValueError("fvqa ops need contiguous tensors")
         dev = dev or t.device
         if t.device != dev:
@@ -59,8 +63,8 @@ _GEMM_WS = {}
 
 
 def gemm_workspace(device, nbytes: int) -> torch.Tensor:
-    """One grow-only split-K scratch buffer per device (fp32 partial sums, reused by every GEMM
-    on the stream: launches are stream-ordered, so sharing is safe)."""
+    """One grow-only GEMM workspace per device (epoch flags + partial-tile slabs of the persistent kernel, reused by
+    every GEMM on the stream: launches are stream-ordered, so sharing is safe)."""
     ws = _GEMM_WS.get(device)
     if ws is None or ws.numel() < nbytes:
         # zero-filled: the first 4 KiB are the epoch flags of the persistent GEMM (include/fvqa.h), which must
@@ -73,7 +77,8 @@ def gemm_workspace(device, nbytes: int) -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
             tail: Optional[torch.Tensor] = None, m_split: int = 0, variant: int = 0) -> torch.Tensor:
     """out[M,N] = a[M,K] @ b[N,K]^T (+ residual). Rows >= m_split go to `tail` (fp32) when given."""
-    _dev(a, b, out, residual, tail)
+    _dev(a, b, out, residual, rows_strided=True)
+    _dev(tail)
     _need(a.dim() == 2 and b.dim() == 2, "gemm_nt: 2-D operands")
     M, K = a.shape
     N, K2 = b.shape
@@ -100,11 +105,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
         epi = EPI_RESIDUAL
     lib = _lib.load()
     code = dt_code(a.dtype)
-    if variant >= 16:
-        need = ((variant - 16) * M * N * 4 if variant > 17 else 0) + 4096
-    elif variant == 13:
+    if variant == 13:
         need = int(lib.fvqa_gemm_sk_workspace())
-    elif variant in (0, 3, 4, 7, 8, 9, 10, 11):
+    elif variant == 0:
         need = int(lib.fvqa_gemm_workspace(M, N, K, code))
     else:
         need = 0
@@ -113,7 +116,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), _ptr(out), _ptr(residual), _ptr(tail), M, N, K, K, K, N, m_split,
+    ldc = out.stride(0) if out is not None else N
+    _need(residual is None or residual.stride(0) == ldc, "gemm_nt: residual and out must share their row stride")
+    rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), _ptr(out), _ptr(residual), _ptr(tail), M, N, K, a.stride(0), b.stride(0),
+                          ldc, m_split,
                           code, dt_code(out_dtype), epi, variant, _ptr(ws), ws.numel() if ws is not None else 0,
                           _stream())
     if timing is not None:
@@ -121,6 +127,54 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
         key = f"{_DTN[a.dtype]}_{_DTN[out_dtype]}_{'res' if epi else 'none'}_{'fix' if need else 'plain'}"
         timing.append((e0, e1, 2.0 * M * N * K, key))
     _lib.check(rc, "fvqa_gemm_nt")
+    return out
+
+
+def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = False, residual=None, swiglu_ab=None):
+    """out = a @ b^T (+ residual | SwiGLU' epilogue with swiglu_ab) and, on the CUs that launch leaves idle (or right
+    after it), the small product rider_out (<= 16 rows) = rider_a @ rider_b^T (accumulate: fp32 rider_out += product).
+    Operands may be column-block views of wider matrices (rows 16-byte aligned)."""
+    import ctypes as C
+    for t in (a, b, out, residual, swiglu_ab, rider_a, rider_b, rider_out):
+        if t is not None and (not t.is_cuda or t.dim() != 2 or t.stride(1) != 1):
+            raise ValueError("gemm_nt_rider: 2-D device tensors with unit inner stride")
+    M, K = a.shape
+    N = b.shape[0]
+    _need(b.shape[1] == K and a.dtype == b.dtype == rider_a.dtype == rider_b.dtype, "gemm_nt_rider: operands")
+    epi, R, ldc = EPI_NONE, None, out.stride(0)
+    if swiglu_ab is not None:
+        _need(tuple(out.shape) == (M, 2 * N) and swiglu_ab.shape == out.shape and out.is_contiguous() and
+              swiglu_ab.is_contiguous(), "gemm_nt_rider: SwiGLU' operands")
+        epi, R = EPI_SWIGLU_BWD, swiglu_ab
+    else:
+        _need(tuple(out.shape) == (M, N), "gemm_nt_rider: out shape")
+        if residual is not None:
+            _need(residual.shape == out.shape and residual.stride(0) == ldc, "gemm_nt_rider: residual")
+            epi, R = EPI_RESIDUAL, residual
+    M2, K2 = rider_a.shape
+    N2 = rider_b.shape[0]
+    _need(rider_b.shape[1] == K2 and tuple(rider_out.shape) == (M2, N2) and M2 <= 16, "gemm_nt_rider: rider shapes")
+    acc = bool(accumulate)
+    if acc:
+        _need(rider_out.dtype == torch.float32 and rider_out.stride(0) == N2,
+              "gemm_nt_rider: an accumulated rider_out is contiguous fp32")
+    else:
+        _need(rider_out.dtype == a.dtype, "gemm_nt_rider: rider_out dtype")
+    rd = _lib.SkRider(rider_a.data_ptr(), rider_b.data_ptr(), rider_out.data_ptr(), M2, N2, K2, rider_a.stride(0),
+                      rider_b.stride(0), rider_out.stride(0), 1 if acc else 0)
+    lib = _lib.load()
+    ws = gemm_workspace(a.device, int(lib.fvqa_gemm_sk_workspace()))
+    timing = GEMM_TIMING
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.fvqa_gemm_nt_rider(_ptr(a), _ptr(b), _ptr(out), _ptr(R), M, N, K, a.stride(0), b.stride(0), ldc,
+                                dt_code(a.dtype), dt_code(out.dtype), epi, C.addressof(rd), _ptr(ws), ws.numel(),
+                                _stream())
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_rider"))
+    _lib.check(rc, "fvqa_gemm_nt_rider")
     return out
 
 
@@ -142,32 +196,6 @@ def gemm_timing_read():
     return [(float(us[i]), float(fl[i]), int(kd[i])) for i in range(min(n, got))]
 
 
-def gemm_nt_partial(a: torch.Tensor, b: torch.Tensor):
-    """a[M,K] @ b[N,K]^T left as fp32 split-K partial sums: returns (ws, splits) with ws a
-    (splits, M, N) fp32 view of the shared GEMM workspace, to be consumed by sumres_rmsnorm_fwd /
-    sum_rmsnorm_bwd before the next GEMM on the stream."""
-    _dev(a, b)
-    _need(a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1] and a.dtype == b.dtype, "gemm_nt_partial: shapes")
-    M, K = a.shape
-    N = b.shape[0]
-    lib = _lib.load()
-    code = dt_code(a.dtype)
-    splits = int(lib.fvqa_gemm_splits(M, N, K, code))
-    need = splits * M * N * 4
-    ws = gemm_workspace(a.device, need)
-    timing = GEMM_TIMING
-    if timing is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), None, None, None, M, N, K, K, K, N, M, code, code, EPI_PARTIAL, 0,
-                          _ptr(ws), ws.numel(), _stream())
-    if timing is not None:
-        e1.record()
-        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[a.dtype]}_none_partial"))
-    _lib.check(rc, "fvqa_gemm_nt(partial)")
-    return ws[:need].view(torch.float32).view(splits, M, N), splits
-
-
 def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, dab: torch.Tensor):
     """dab (M, 2*Hf) = d/d(a,b)[silu(a)*b] with dz = g (M,D) @ w2_t (Hf,D)^T formed in the GEMM
     accumulators (the SwiGLU backward is the GEMM's epilogue; dz never reaches HBM)."""
@@ -178,8 +206,8 @@ def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, da
     _need(ab.numel() >= M * 2 * N and dab.numel() >= M * 2 * N and ab.shape[-1] == 2 * N and dab.shape[-1] == 2 * N,
           "gemm_nt_swiglu_bwd: ab/dab shape")
     lib = _lib.load()
-    need = int(lib.fvqa_gemm_workspace(M, N, K, dt_code(g.dtype)))      # tail-round plan of multi-stream shapes
-    ws = gemm_workspace(g.device, need) if need else None
+    need = int(lib.fvqa_gemm_sk_workspace())                 # this epilogue lives in the persistent kernel
+    ws = gemm_workspace(g.device, need)
     timing = GEMM_TIMING
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -195,45 +223,6 @@ def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, da
 
 
 # ------------------------------------------------------------------------------------ row ops
-def sumres_rmsnorm_fwd(ws, resid, w, h, y, rstd, eps: float, rows: int, tail_src=None):
-    """h = round(resid + sum_s ws[s]); y = RMSNorm(h) * w  (first `rows` rows); tail_src (n, dim) fp32: rows
-    [rows, rows+n) of y <- storage-dtype cast of tail_src (the next layer's adapter rows)."""
-    _dev(ws, resid, w, h, y, rstd, tail_src)
-    tail_rows = 0
-    if tail_src is not None:
-        tail_rows = tail_src.shape[0]
-        _need(tail_src.dtype == torch.float32 and tail_src.dim() == 2 and tail_src.shape[1] == ws.shape[2] and
-              tail_src.is_contiguous() and y.numel() >= (rows + tail_rows) * ws.shape[2], "sumres_rmsnorm_fwd: tail_src")
-    splits, Mt, dim = ws.shape
-    _need(ws.dtype == torch.float32 and rows <= Mt, "sumres_rmsnorm_fwd: ws")
-    _need(resid.dtype == w.dtype == h.dtype == y.dtype and w.numel() == dim, "sumres_rmsnorm_fwd: dtype")
-    for t in (resid, h, y):
-        _need(t.shape[-1] == dim and t.numel() >= rows * dim, "sumres_rmsnorm_fwd: rows")
-    _need(rstd.dtype == torch.float32 and rstd.numel() >= rows, "sumres_rmsnorm_fwd: rstd")
-    rc = _lib.load().fvqa_sumres_rmsnorm_fwd(_ptr(ws), splits, Mt * dim, _ptr(resid), _ptr(w), _ptr(h), _ptr(y),
-                                             _ptr(rstd), rows, dim, float(eps), _ptr(tail_src), tail_rows,
-                                             dt_code(h.dtype), _stream())
-    _lib.check(rc, "fvqa_sumres_rmsnorm_fwd")
-
-
-def sum_rmsnorm_bwd(ws, x, w, rstd, dx, rows: int, resid=None, tail=None):
-    """dx = resid + rmsnorm_bwd(sum_s ws[s]); partial rows >= `rows` are added into `tail` (fp32)."""
-    _dev(ws, x, w, rstd, dx, resid, tail)
-    splits, Mt, dim = ws.shape
-    tail_rows = 0 if tail is None else Mt - rows
-    _need(ws.dtype == torch.float32 and rows <= Mt, "sum_rmsnorm_bwd: ws")
-    _need(x.dtype == w.dtype == dx.dtype and w.numel() == dim, "sum_rmsnorm_bwd: dtype")
-    for t in (x, dx, resid):
-        _need(t is None or (t.dtype == x.dtype and t.shape[-1] == dim and t.numel() >= rows * dim), "sum_rmsnorm_bwd: rows")
-    _need(rstd.dtype == torch.float32 and rstd.numel() >= rows, "sum_rmsnorm_bwd: rstd")
-    _need(tail is None or (tail.dtype == torch.float32 and tuple(tail.shape) == (tail_rows, dim) and tail_rows > 0),
-          "sum_rmsnorm_bwd: tail")
-    rc = _lib.load().fvqa_sum_rmsnorm_bwd(_ptr(ws), splits, Mt * dim, _ptr(x), _ptr(w), _ptr(rstd), _ptr(resid),
-                                          _ptr(dx), _ptr(tail), tail_rows, rows, dim, dt_code(x.dtype), _stream())
-    _lib.check(rc, "fvqa_sum_rmsnorm_bwd")
-
-
-
 def rmsnorm_fwd(x, w, y, rstd, eps: float, rows: Optional[int] = None):
     _dev(x, w, y, rstd)
     dim = x.shape[-1]

@@ -80,7 +80,7 @@ class Arena:
         self.xs = e(L + 1, R, D)
         self.rstd1 = e(L, R, dtype=f32)
         self.rstd2 = e(L, R, dtype=f32)
-        self.qkv = e(L, Ra, 3 * D)
+        self.qkv = torch.zeros(L, Ra, 3 * D, dtype=dt, device=dev)   # (the q block of the adapter rows is never written)
         self.o = e(L, R, D)
         self.lse_a = e(L, n_seq * H * S, dtype=f32)
         self.lse_t = e(L, n_seq * H * S, dtype=f32)
@@ -297,8 +297,9 @@ class StepEngine:
         ops.rmsnorm_fwd(ar.xs[0], pk.an[0], ar.xn, ar.rstd1[0], self.eps, rows=R)
         for i in range(L):
             x = ar.xs[i]
-            ops.gemm_nt(ar.xn, pk.wqkv[i], ar.qkv[i][:R])
-            ops.gemm_nt(ar.adapter_c[i], pk.wqkv[i], ar.qkv[i][R:])       # adapter K/V rows (model.py:98-100)
+            # sequence rows, and on the idle CUs the K/V projections of the adapter rows (model.py:98-100)
+            ops.gemm_nt_rider(ar.xn, pk.wqkv[i], ar.qkv[i][:R], rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:],
+                              rider_out=ar.qkv[i][R:, D:])
             g1, g2 = m.gate_views(i)
             if ops.attn_rope_fused(self.dtype):             # bf16 MFMA build: q,k stay raw, rotated inside
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F,
@@ -369,7 +370,11 @@ class StepEngine:
         ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
         g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
         for i in reversed(range(L)):
-            ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab)      # dz·SwiGLU' fused in the epilogue
+            if i + 1 < L:                    # dz·SwiGLU' in the epilogue; rider: the previous layer's adapter-grad rows
+                ops.gemm_nt_rider(cur, pk.w2_t[i], ar.dab, swiglu_ab=ar.ab[i], rider_a=ar.dqkv[R:, D:],
+                                  rider_b=pk.wqkv_t[i + 1][:, D:], rider_out=g_adapter[i + 1], accumulate=True)
+            else:
+                ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab)
             ops.gemm_nt(ar.dab, pk.w13_t[i], t)
             ops.rmsnorm_bwd(t, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
             ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)
@@ -383,9 +388,10 @@ class StepEngine:
                              dg2, ar.attn_ws, n_seq, S, H, Dh, A, F)
                 ops.rope_qk(ar.dqkv, self.cos, self.sin, n_seq, S, H, Dh, inverse=True)
             ops.gemm_nt(ar.dqkv[:R], pk.wqkv_t[i], t)
-            ops.gemm_nt(ar.dqkv[R:], pk.wqkv_t[i], None, tail=g_adapter[i], m_split=0)   # adapter-query grad rows (+=)
             ops.rmsnorm_bwd(t, ar.xs[i], pk.an[i], ar.rstd1[i], nxt, resid=ar.dh, rows=R)
             cur, nxt = nxt, cur
+        # layer 0's adapter-query gradient rows (+=): nothing left to ride on
+        ops.gemm_nt(ar.dqkv[R:, D:], pk.wqkv_t[0][:, D:], None, tail=g_adapter[0], m_split=0)
         return cur
 
 

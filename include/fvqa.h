@@ -41,9 +41,6 @@ extern "C" {
 #define FVQA_EPI_RESIDUAL 1 /* C = acc + R                                  */
 #define FVQA_EPI_SWIGLU_BWD 3 /* acc = dz (M,N): R = ab (M,2N: a|b), C = dab (M,2N) <- d/d(a,b) of
                                 silu(a)*b (llama/model.py:142 backward); ldc must be 2N     */
-#define FVQA_EPI_PARTIAL 2  /* no C: leave the fp32 split-K partial sums [splits][M][N] in
-                               `workspace` for a fused consumer (fvqa_sumres_rmsnorm_fwd,
-                               fvqa_sum_rmsnorm_bwd); splits = fvqa_gemm_splits(M,N,K,dtype) */
 
 int fvqa_version(void);      /* ABI version, bumped on any signature change */
 const char* fvqa_arch(void); /* "gfx950"                                     */
@@ -56,19 +53,19 @@ const char* fvqa_arch(void); /* "gfx950"                                     */
  * (FVQA_F32 for LM-head logits). Rows m >= m_split (if tail != NULL) are written as fp32 to
  * tail[(m - m_split)*N + n] (ACCUMULATED, +=) instead of C (adapter-query gradient rows).
  * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows.
- * variant 0 picks the kernel: 256x256-tile 4-stage LDS-DMA ring (+ split-K through `workspace`
- * when the output has too few tiles for 256 CUs), the 128x128-tile kernel for small problems, or — bf16,
- * M <= 16, K % 256 == 0 — the weight-streaming kernel of the generation path (one new token per
- * sequence; llama/model.py:439-447 run row-wise). Other variant codes force a kernel (tests, tuning). */
+ * variant 0 picks the kernel: the persistent 256x256-tile LDS-DMA ring kernel (M >= 192, N >= 256, N % 8 == 0, no
+ * tail rows, workspace given), the weight-streaming kernel of the generation path for bf16 M <= 16, K % 256 == 0 (one
+ * new token per sequence, llama/model.py:439-447 run row-wise; with C == NULL, m_split == 0 it accumulates every row
+ * into `tail`: the adapter-query gradient rows), else the 128x128-tile kernel. Other variant codes force a kernel
+ * (1 / 2 = 128x128 register- / DMA-staged, 12 = weight-streaming, 13 = persistent; tests, tuning). */
 int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* tail,
                  int M, int N, int K, int lda, int ldb, int ldc, int m_split,
                  int dtype, int out_dtype, int epilogue, int variant,
                  void* workspace, size_t workspace_bytes, void* stream);
-/* fvqa_gemm_workspace: bytes of `workspace` that serve whichever kernel variant 0 picks for the problem.
- * Its FIRST 4096 BYTES are the epoch flags of the work-balanced persistent kernel (csrc/gemm_sk.hip): the caller
- * zeroes them ONCE after allocating the buffer; no call ever needs them reset. One workspace serves one stream at
- * a time. fvqa_gemm_splits: K-splits of the older plane path (FVQA_EPI_PARTIAL). */
-int fvqa_gemm_splits(int M, int N, int K, int dtype);
+/* fvqa_gemm_workspace: bytes of `workspace` the kernel variant 0 picks for the problem needs (0: none).
+ * Its FIRST 4096 BYTES are the epoch flags of the persistent kernel (csrc/gemm_sk.hip): the caller zeroes them ONCE
+ * after allocating the buffer (256-byte aligned); no call ever needs them reset. One workspace serves one stream at
+ * a time. */
 size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
 /* The persistent kernel (variant 0 for M >= 192, N >= 256, N % 8 == 0, no tail rows; variant 13 forces it): a grid of
  * at most one workgroup per CU walks whole 256x256 output tiles, or — outputs with few tiles — one K range of a tile
@@ -80,6 +77,23 @@ size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
  * rounds of whole tiles, tiles of the last (split) round, pieces per tile there}; for team >= 0 also its segments, 5 ints each
  * {tile, k0, k1, pieces n, piece c} (up to max_segs written); returns the team's segment count. */
 size_t fvqa_gemm_sk_workspace(void);
+
+/* A second, independent product of at most 16 rows, C2[M2,N2] = A2[M2,K2] · B2[N2,K2]^T (operands in the main
+ * problem's `dtype`), that rides on the compute units a projection leaves idle: the 10 adapter rows of
+ * llama/model.py:98-100 (their K/V projections beside the QKV GEMM; their gradient rows into adapter_query.grad
+ * beside the W2^T GEMM of the next layer walked). accumulate_f32 == 0: C2 has the storage dtype and is overwritten;
+ * != 0: C2 is fp32 and the product is ADDED (ldc2 must then equal N2). */
+typedef struct fvqa_sk_rider {
+  const void* A; const void* B; void* C;
+  int32_t M, N, K, lda, ldb, ldc;
+  int32_t accumulate_f32;
+} fvqa_sk_rider;
+/* C = A·B^T (+ epilogue) exactly as fvqa_gemm_nt variant 0 (no tail rows), plus `rider`: inside the same launch when the
+ * persistent kernel takes the main problem and leaves >= 16 CUs idle (bf16, M2 <= 16, K2 % 256 == 0), else as its
+ * own launch right after it. The arithmetic of the rider is the same in both cases (bitwise-equal results). */
+int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
+                       int ldc, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider,
+                       void* workspace, size_t workspace_bytes, void* stream);
 int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
                           int32_t* segs_out, int max_segs);
 /* Measurement probe (bench.py roofline; no reference counterpart): while enabled, every launch of the
@@ -87,7 +101,8 @@ int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* pla
  * passes are outside the pair). fvqa_gemm_timing_read synchronises, returns the number of launches
  * recorded since enable and fills up to `max` entries: duration (us), algorithmic FLOPs (2*M*N*K of
  * that launch) and kind = epilogue | split_k << 4 | out_is_f32 << 5 | in_is_f32 << 6; it then clears
- * the record (max <= 0: size query only, nothing cleared). enable(0) stops recording. Not thread-safe; one measuring host thread. */
+ * the record (max <= 0: size query only, nothing cleared). enable(0) stops recording and frees the probe. Launches from
+ * any host thread are recorded (the step's backward runs on the autograd thread); switch it while no launch is in flight. */
 int fvqa_gemm_timing_enable(int on);
 int fvqa_gemm_timing_read(int max, float* us, double* flops, int* kind);
 
@@ -97,19 +112,6 @@ int fvqa_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int row
 /* dx = (resid ? resid : 0) + rmsnorm_bwd(g; x, w, rstd)   (weight frozen ⇒ no dw) */
 int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, const float* rstd,
                      const void* resid, void* dx, int rows, int dim, int dtype, void* stream);
-
-/* Fused consumers of FVQA_EPI_PARTIAL GEMMs (plane = M_total*dim elements between splits):
- * h = round(resid + sum_s ws[s]) (the residual stream, llama/model.py:185-186), y = RMSNorm(h)*w;
- * rows [rows, rows+tail_rows) of y receive the storage-dtype cast of the fp32 `tail_src` rows
- * (the next layer's adapter prompt riding under the sequence rows, llama/model.py:339). */
-int fvqa_sumres_rmsnorm_fwd(const float* ws, int splits, size_t plane, const void* resid,
-                            const void* w, void* h, void* y, float* rstd, int rows, int dim,
-                            float eps, const float* tail_src, int tail_rows, int dtype, void* stream);
-/* dx = resid + rmsnorm_bwd(sum_s ws[s]; x, w, rstd); rows [rows, rows+tail_rows) of the partials
- * are added into the fp32 `tail` (adapter-query gradient rows) */
-int fvqa_sum_rmsnorm_bwd(const float* ws, int splits, size_t plane, const void* x, const void* w,
-                         const float* rstd, const void* resid, void* dx, float* tail, int tail_rows,
-                         int rows, int dim, int dtype, void* stream);
 
 /* ---- RoPE on the q and k column blocks of a fused qkv buffer (llama/model.py:61-67,96).
  * qkv is (rows, 3*dim) with q at cols [0,dim), k at [dim,2dim). cos/sin are (S, head_dim/2)

@@ -38,6 +38,11 @@ CASES = {
     # BASELINE configs[0] (C1): the full 32-layer 7B, B=2, S=128, all three losses (~30 GB of fp32
     # weights in the reference: generated tensor by tensor; a few minutes on 8 cores)
     "7b_full_all": ("7b", dict(batch_size=2, vaq=True, qav=True)),
+    # the BENCHMARK shapes at 7B / 13B width, two layers deep (BASELINE configs[1..4]):
+    "7b_l2_b8_vqa": ("7b_l2", dict(batch_size=8, vaq=False, qav=False)),                       # C2: B=8, VQA only
+    "7b_l2_b8_all": ("7b_l2", dict(batch_size=8, vaq=True, qav=True)),                         # C3: B=8, 24 sequences
+    "7b_l2_s650_all": ("7b_l2", dict(batch_size=1, max_seq_len=650, vaq=True, qav=True)),      # C4: TVQA-shape context
+    "13b_l2_all": ("13b", dict(n_layers=2, adapter_layer=2, batch_size=4, vaq=True, qav=True)),  # C5: D=5120, H=40
 }
 
 

@@ -24,6 +24,7 @@
 #include "gemm_skinny.h"
 #include "probe.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace {
 using namespace fvqa_ring;
@@ -415,7 +416,8 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   a.epoch = g_epoch.fetch_add(1) + 1;
   a.rider = SkRider{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
   const int idle = (n_cu < 256 ? n_cu : 256) - a.plan.n_teams * a.plan.ts;
-  if (rider && dtype == FVQA_BF16 && idle >= 16 && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 &&
+  static const bool ride = !(getenv("FVQA_RIDER") && getenv("FVQA_RIDER")[0] == '0');   // tuning: FVQA_RIDER=0 keeps riders as own launches
+  if (ride && rider && dtype == FVQA_BF16 && idle >= 16 && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 &&
       rider->N > 0 && rider->A && rider->B && rider->C) {
     const int strips = (rider->N + 15) / 16;
     a.rider = SkRider{rider->A, rider->B, rider->C, rider->M, rider->N, rider->K, rider->lda, rider->ldb, rider->ldc,

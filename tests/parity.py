@@ -18,6 +18,11 @@ CASES = {
     # BASELINE configs[0]: the full 32-layer 7B, B=2, S=128, three losses (GPU parity only: the fp64
     # oracle of this size does not fit the CPU test budget)
     "7b_full_all": ("7b", dict(batch_size=2, vaq=True, qav=True)),
+    # the benchmark shapes at 7B / 13B width, two layers deep (BASELINE configs[1..4])
+    "7b_l2_b8_vqa": ("7b_l2", dict(batch_size=8, vaq=False, qav=False)),
+    "7b_l2_b8_all": ("7b_l2", dict(batch_size=8, vaq=True, qav=True)),
+    "7b_l2_s650_all": ("7b_l2", dict(batch_size=1, max_seq_len=650, vaq=True, qav=True)),
+    "13b_l2_all": ("13b", dict(n_layers=2, adapter_layer=2, batch_size=4, vaq=True, qav=True)),
 }
 
 
@@ -31,18 +36,25 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, margin_factor=4.0,
-                        check_argmax=True):
+def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, tol=None, check_argmax=True,
+                        min_decided=0.0):
     """losses: dict task->float; grads: dict name->tensor (CPU); logits: dict task->(N,S,V) tensor;
     layer_out: list in the reference's hook order (layer-major, stream-minor) of (N,S,D) tensors.
+    rtol bounds every quantity unless `tol` gives its own bound for "loss" / "logits" / "layer" / "grad".
+    Token argmax must equal the reference's on every DECIDED row: a row whose reference top-2 margin exceeds the band
+    the MEASURED logit error allows (8 x the largest sampled error, at least 2e-5 of the logit range) — rows inside
+    that band are ties, not mismatches; min_decided is the least fraction of rows that must be decided.
     Returns a dict of measured errors; raises AssertionError on the first violation."""
+    tol = dict(tol or {})
+    t_loss, t_logit = tol.get("loss", rtol), tol.get("logits", rtol)
+    t_layer, t_grad = tol.get("layer", rtol), tol.get("grad", rtol)
     rep = {}
     for t in ("vqa", "vaq", "qav"):
         ref = float(g[f"loss_{t}"])
         got = float(losses[t])
         err = abs(got - ref) / max(abs(ref), 1e-12) if ref != 0 else abs(got)
         rep[f"loss_{t}"] = err
-        assert err <= rtol, f"loss_{t}: got {got} ref {ref} rel {err:.3e} > {rtol}"
+        assert err <= t_loss, f"loss_{t}: got {got} ref {ref} rel {err:.3e} > {t_loss}"
     if logits is not None:
         for t in ("vqa", "vaq"):
             if f"argmax_{t}" not in g or t not in logits:
@@ -55,14 +67,16 @@ def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, 
             amax = float(g[f"logits_absmax_{t}"])
             err = float(np.abs(got - g[f"sample_logits_{t}"]).max() / amax)
             rep[f"logits_{t}"] = err
-            assert err <= rtol, f"logits_{t}: max abs err / absmax = {err:.3e} > {rtol}"
+            assert err <= t_logit, f"logits_{t}: max abs err / absmax = {err:.3e} > {t_logit}"
             if check_argmax:
                 am = flat.argmax(-1).numpy()
-                # rows whose reference top-2 margin is inside the error band are ties, not mismatches
-                decided = g[f"margin_{t}"] > margin_factor * rtol * amax
+                band = max(8.0 * err, 2e-5) * amax
+                decided = g[f"margin_{t}"] > band
                 bad = (am != g[f"argmax_{t}"]) & decided
-                rep[f"argmax_{t}_decided"] = int(decided.sum())
+                frac = float(decided.mean())
+                rep[f"argmax_{t}_decided"] = f"{int(decided.sum())}/{decided.size}"
                 assert not bad.any(), f"argmax_{t}: {int(bad.sum())} of {int(decided.sum())} decided rows differ"
+                assert frac >= min_decided, f"argmax_{t}: only {frac:.3f} of the rows are decided (band {band:.3e})"
     if layer_out is not None:
         cs, pick = g["layer_checksum"], g["layer_pick"]
         assert len(layer_out) == cs.shape[0], (len(layer_out), cs.shape)
@@ -74,7 +88,7 @@ def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, 
             scale = nrm / np.sqrt(f.numel())
             e_pick = float(np.abs(f[torch.from_numpy(pick[i])].numpy() - cs[i, 2:]).max() / scale)
             worst = max(worst, e_norm, e_pick)
-            assert e_norm <= rtol and e_pick <= 4 * rtol, f"layer_out[{i}]: norm {e_norm:.3e} pick {e_pick:.3e}"
+            assert e_norm <= t_layer and e_pick <= 4 * t_layer, f"layer_out[{i}]: norm {e_norm:.3e} pick {e_pick:.3e}"
         rep["layer_out"] = worst
     for k in g:
         if not k.startswith("gradnorm__"):
@@ -94,5 +108,5 @@ def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, 
             ref = g[f"gradsample__{key}"]
             e = max(e, float(np.abs(gr.flatten()[pk].numpy() - ref).max() / np.abs(ref).max()))
         rep[f"grad:{name}"] = e
-        assert e <= rtol, f"grad {name}: rel err {e:.3e} > {rtol}"
+        assert e <= t_grad, f"grad {name}: rel err {e:.3e} > {t_grad}"
     return rep

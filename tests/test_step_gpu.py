@@ -19,20 +19,51 @@ BF16_LOSS_RTOL = 2e-2   # bf16 storage (8-bit mantissa) through L layers
 BF16_GRAD_RTOL = 8e-2
 
 
-@pytest.mark.parametrize("case", ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "7b_l2_all", "7b_l2_vqa",
-                                  "7b_full_all"])
+# every BASELINE shape has a golden: C1 = 7b_full_all (full depth), C2 = 7b_l2_b8_vqa, C3 = 7b_l2_b8_all,
+# C4 = 7b_l2_s650_all, C5 = 13b_l2_all (benchmark width and batch, two layers deep)
+GOLDEN_CASES = ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "7b_l2_all", "7b_l2_vqa", "7b_full_all",
+                "7b_l2_b8_vqa", "7b_l2_b8_all", "7b_l2_s650_all", "13b_l2_all"]
+# against the reference's golden the bf16 build measures (profiles/r02_parity_vs_golden.log): losses <= 3.1e-4, sampled
+# logits <= 7.5e-3 of the logit range, gradients <= 2.0e-2; the bounds below leave about 2.5x
+BF16_TOL = dict(loss=5e-3, logits=2e-2, layer=3e-2, grad=5e-2)
+
+
+def _free(model):
+    import gc
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_fp32_step_matches_reference_golden(case):
     pname, over = CASES[case]
     cfg = synth.preset(pname, **over)
     model, _ = build_model(cfg, torch.float32)
     batch = synth.make_batch(cfg, seed=0)
     losses, grads, logits, layer_out = run_step(model, batch)
-    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=FP32_RTOL)
+    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=FP32_RTOL, min_decided=0.99)
     print(case, {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
     # the fp32 build is in fact far inside the bar
     assert rep["loss_vqa"] < 1e-4
-    del model
-    torch.cuda.empty_cache()
+    _free(model)
+
+
+@pytest.mark.parametrize("case", ["small_all", "7b_l2_all", "7b_full_all", "7b_l2_b8_vqa", "7b_l2_b8_all",
+                                  "7b_l2_s650_all", "13b_l2_all"])
+def test_bf16_step_against_reference_golden(case):
+    """The PRODUCTION build (bf16 storage, MFMA attention) against the reference's own results at the benchmark's
+    shapes: losses within 5e-3, sampled logits within 2e-2 of the logit range, gradients within 5e-2 (max-abs over
+    max-abs / norms; bf16 keeps 8 mantissa bits and the frozen weights themselves are rounded), and the token argmax
+    equal on every row whose reference top-2 margin exceeds 8 x the measured logit error."""
+    pname, over = CASES[case]
+    cfg = synth.preset(pname, **over)
+    model, _ = build_model(cfg, torch.bfloat16)
+    batch = synth.make_batch(cfg, seed=0)
+    losses, grads, logits, layer_out = run_step(model, batch)
+    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=BF16_LOSS_RTOL, tol=BF16_TOL)
+    print(case, {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
+    _free(model)
 
 
 def _oracle(cfg, sd, batch, weights=(1.0, 1.0, 1.0)):
@@ -154,17 +185,25 @@ def test_native_schedule_equals_python_schedule(dtype, monkeypatch):
         assert torch.equal(g_nat[n], g_py[n]), n
 
 
-def test_step_is_bitwise_repeatable():
-    """Same inputs twice -> bitwise equal losses and gradients (no atomics anywhere): the cheap
-    race detector SURVEY §5 asks for."""
-    cfg = synth.preset("small", vaq=True, qav=True)
+@pytest.mark.parametrize("pname,over", [("small", dict(vaq=True, qav=True)),
+                                        ("7b_l2", dict(batch_size=8, vaq=True, qav=True)),      # C3: 24 sequences, H=32
+                                        ("7b_l2", dict(batch_size=8, vaq=False, qav=False))])   # C2
+def test_step_is_bitwise_repeatable(pname, over):
+    """Same inputs three times -> bitwise equal losses, logits and gradients: no floating-point atomics anywhere, the
+    in-launch reductions (split-K tiles, attention-backward batch sums) run in a fixed order whichever workgroup
+    arrives last. At the benchmark's width and batch (n_seq = 8 and 24) as well as the small preset."""
+    cfg = synth.preset(pname, **over)
     model, _ = build_model(cfg, torch.bfloat16)
     batch = synth.make_batch(cfg, seed=4)
-    l1, g1, _, _ = run_step(model, batch)
-    l2, g2, _, _ = run_step(model, batch)
-    assert l1 == l2
-    for n in g1:
-        assert torch.equal(g1[n], g2[n]), n
+    l1, g1, lg1, _ = run_step(model, batch)
+    for _ in range(2):
+        l2, g2, lg2, _ = run_step(model, batch)
+        assert l1 == l2
+        for t in lg1:
+            assert torch.equal(lg1[t], lg2[t]), t
+        for n in g1:
+            assert torch.equal(g1[n], g2[n]), n
+    _free(model)
 
 
 def test_ragged_long_sequence_properties():

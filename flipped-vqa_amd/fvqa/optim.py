@@ -29,7 +29,11 @@ class FusedAdamW(torch.optim.Optimizer):
     The update is skipped on device when `found_inf` is set (GradScaler semantics)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, *, flat):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # the param-group keys of torch.optim.AdamW (what the reference's optimizer.state_dict() carries and what its
+        # load_state_dict expects back): a checkpoint written here loads into the reference's torch AdamW and back
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False,
+                                      fused=None, decoupled_weight_decay=True))
         self.flat = flat
         dev = flat.flat.device
         self.exp_avg = torch.zeros_like(flat.flat)

@@ -215,6 +215,7 @@ class NativeScalerWithGradNormCount:
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
         self.enabled = enabled
         self._init_scale = init_scale if enabled else 1.0
+        self._init_tracker = 0
         self._dev = None
         self._torch_scaler = None
 
@@ -222,7 +223,7 @@ class NativeScalerWithGradNormCount:
         if self._dev is None:
             f = dict(dtype=torch.float32, device=device)
             self._scale = torch.full((1,), self._init_scale, **f)
-            self._tracker = torch.zeros(1, **f)
+            self._tracker = torch.full((1,), float(self._init_tracker), **f)
             self._found = torch.zeros(1, **f)
             self._norm = torch.zeros(1, **f)
             self._dev = device
@@ -272,7 +273,7 @@ class NativeScalerWithGradNormCount:
         if self._torch_scaler is not None:
             return self._torch_scaler.state_dict()
         scale = float(self._scale.item()) if self._dev is not None else self._init_scale
-        tracker = int(self._tracker.item()) if self._dev is not None else 0
+        tracker = int(self._tracker.item()) if self._dev is not None else self._init_tracker
         return {"scale": scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
                 "growth_interval": self.growth_interval, "_growth_tracker": tracker}
 
@@ -283,9 +284,10 @@ class NativeScalerWithGradNormCount:
         self.growth_factor = state_dict.get("growth_factor", self.growth_factor)
         self.backoff_factor = state_dict.get("backoff_factor", self.backoff_factor)
         self.growth_interval = state_dict.get("growth_interval", self.growth_interval)
+        self._init_tracker = int(state_dict.get("_growth_tracker", 0))    # applied now or at the first call (lazy device state)
         if self._dev is not None:
             self._scale.fill_(self._init_scale)
-            self._tracker.fill_(float(state_dict.get("_growth_tracker", 0)))
+            self._tracker.fill_(float(self._init_tracker))
 
 
 # ------------------------------------------------------------------------------ checkpoints

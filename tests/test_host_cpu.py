@@ -138,6 +138,23 @@ def test_merge_shards_follows_meta_split_dims():
     assert llama_vqa.merge_shards([full], 1) is full
 
 
+def test_merge_shards_equals_the_reference_merge(golden_dir):
+    """tests/golden/ckpt_merge.npz: a synthetic 2-shard Meta checkpoint (fp16, with rope.freqs) and what the merge loop
+    INSIDE the reference's llama_vqa.LLaMA_VQA (llama_vqa.py:24-58) made of it (oracle/gen_golden_ckpt.py ran that
+    function itself). The product's merge must give the same keys, dtypes and bits."""
+    import numpy as np
+    g = dict(np.load(os.path.join(golden_dir, "ckpt_merge.npz")))
+    keys = [str(k) for k in g["shard_keys"]]
+    shards = [{k: torch.from_numpy(g[f"shard{r}__{k}"]) for k in keys} for r in range(2)]
+    merged = llama_vqa.merge_shards(shards, int(g["n_layers"]))
+    want = [str(k) for k in g["merged_keys"]]
+    assert set(merged) == set(want) and "rope.freqs" not in merged
+    for k in want:
+        ref = torch.from_numpy(g[f"merged__{k}"])
+        assert merged[k].dtype == ref.dtype == torch.float16 and merged[k].shape == ref.shape, k
+        assert torch.equal(merged[k], ref), k
+
+
 def test_shard_indices_match_distributed_sampler():
     from torch.utils.data import DistributedSampler
     ds = list(range(23))

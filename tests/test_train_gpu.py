@@ -128,3 +128,102 @@ def test_gates_of_skipped_layers_are_left_alone():
     assert all(not torch.equal(g.detach(), b) for g, b in zip(g_live, before_live))
     for off in flat.idle_offsets():
         assert float(opt.exp_avg[off:off + cfg.n_heads].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------ checkpoint interchange
+def _ckpt_setup():
+    from oracle.gen_golden_ckpt import CKPT_CFG          # the configuration the reference-written fixture was made at
+    cfg = synth.SynthConfig(**CKPT_CFG)
+    model, args = build_model(cfg, torch.float32)
+    opt = FusedAdamW(param_groups_weight_decay(model, 0.14), lr=0.01, betas=(0.9, 0.95), flat=model.flat_params())
+    return cfg, model, args, opt
+
+
+def test_resume_from_a_checkpoint_written_by_the_reference(golden_dir):
+    """tests/golden/ckpt_reference.pth was written by the reference's own util.misc.save_model after ONE optimizer step
+    of the reference model (torch AdamW + its GradScaler wrapper; oracle/gen_golden_ckpt.py). The product resumes from
+    that file — trainables, AdamW moments and step, loss-scale state, start epoch — and its NEXT step must land where
+    the reference's own next step landed (reference util/misc.py:297-336)."""
+    import json
+    import os
+    import numpy as np
+    g = dict(np.load(os.path.join(golden_dir, "ckpt_reference.npz")))
+    cfg, model, args, opt = _ckpt_setup()
+    scaler = misc.NativeScalerWithGradNormCount()
+    args.resume = os.path.join(golden_dir, "ckpt_reference.pth")
+    misc.load_model(args, model, opt, scaler)
+    assert args.start_epoch == int(g["epoch"]) + 1 == 4
+    own = dict(model.named_parameters())
+    names = [str(n) for n in g["model_keys"]]
+    assert names == [n for n, p in model.named_parameters() if p.requires_grad]       # the reference's key set and order
+    for n in names:
+        assert torch.equal(own[n].detach().cpu(), torch.from_numpy(g[f"model__{n}"]).view_as(own[n])), n
+    # optimizer: index i of the reference's state dict is the i-th trainable in timm group order
+    assert [str(n) for n in g["opt_param_names"]] == names
+    for i, n in enumerate(names):
+        st = opt.state[own[n]]
+        assert torch.equal(st["exp_avg"].cpu(), torch.from_numpy(g[f"state__{i}__exp_avg"])), n
+        assert torch.equal(st["exp_avg_sq"].cpu(), torch.from_numpy(g[f"state__{i}__exp_avg_sq"])), n
+        assert float(g[f"state__{i}__step"]) == 1.0
+    assert opt.step_dev.item() == 1.0
+    sc = json.loads(str(g["scaler_json"]))
+    assert scaler.state_dict()["scale"] == sc["scale"] == 65536.0
+    # ... and training goes on as the reference's did: one more step on the batch the reference used next
+    for grp in opt.param_groups:
+        assert grp["lr"] == 0.01 and tuple(grp["betas"]) == (0.9, 0.95)
+    before = {n: own[n].detach().clone() for n in names}
+    opt.zero_grad()
+    a, b, c = model(synth.make_batch(cfg, seed=1))
+    scaler(a + b + c, opt, parameters=None, update_grad=True)
+    torch.cuda.synchronize()
+    for got, ref in zip((a, b, c), g["losses_step2"]):
+        assert abs(float(got.detach()) - float(ref)) / float(ref) < 1e-4
+    for n in names:
+        upd_ref = torch.from_numpy(g[f"after2__{n}"]).view_as(own[n]).double() - before[n].double().cpu()
+        upd_got = own[n].detach().double().cpu() - before[n].double().cpu()
+        # AdamW moves every element by ~lr whatever the gradient scale: compare the UPDATES, relative to their size
+        assert float((upd_got - upd_ref).abs().max()) <= 2e-2 * float(upd_ref.abs().max()), n
+        assert float((upd_got - upd_ref).norm()) <= 5e-3 * float(upd_ref.norm()), n
+    assert scaler.state_dict()["_growth_tracker"] == json.loads(str(g["scaler_after2_json"]))["_growth_tracker"] == 2
+
+
+def test_written_checkpoint_has_the_reference_layout(golden_dir, tmp_path):
+    """A checkpoint written by the product after one step: the same top-level keys, trainable names / dtypes / shapes,
+    optimizer state entries and param-group keys, scaler keys as the file the reference wrote (so that either side can
+    load the other's)."""
+    import json
+    import os
+    import numpy as np
+    g = dict(np.load(os.path.join(golden_dir, "ckpt_reference.npz")))
+    cfg, model, args, opt = _ckpt_setup()
+    scaler = misc.NativeScalerWithGradNormCount()
+    opt.zero_grad()
+    a, b, c = model(synth.make_batch(cfg, seed=0))
+    scaler(a + b + c, opt, parameters=None, update_grad=True)
+    for got, ref in zip((a, b, c), g["losses"]):
+        assert abs(float(got.detach()) - float(ref)) / float(ref) < 1e-4       # same model, same batch as the reference's step 1
+    args.output_dir = str(tmp_path)
+    misc.save_model(args, 3, model, model, opt, scaler, "checkpoint_best")
+    ck = torch.load(tmp_path / "checkpoint_best.pth", map_location="cpu", weights_only=False)
+    assert list(ck.keys()) == [str(k) for k in g["top_keys"]]
+    assert list(ck["model"].keys()) == [str(k) for k in g["model_keys"]]
+    for n, t in ck["model"].items():
+        ref = g[f"model__{n}"]
+        assert t.dtype == torch.float32 and tuple(t.shape) == ref.shape, n
+        # one AdamW step from the same start: the product's trainables after step 1 track the reference's
+        assert float((t.double() - torch.from_numpy(ref).double()).abs().max()) <= 2e-2 * 0.01 + 1e-6, n
+    osd = ck["optimizer"]
+    ref_groups = json.loads(str(g["param_groups_json"]))
+    assert len(osd["param_groups"]) == len(ref_groups)
+    for gp, gr in zip(osd["param_groups"], ref_groups):
+        assert set(gp.keys()) == set(gr.keys())
+        assert list(gp["params"]) == gr["params"] and gp["weight_decay"] == gr["weight_decay"]
+        assert gp["lr"] == gr["lr"] and list(gp["betas"]) == gr["betas"] and gp["eps"] == gr["eps"]
+    assert sorted(osd["state"].keys()) == [int(i) for i in g["state_ids"]]
+    for i in osd["state"]:
+        assert list(osd["state"][i].keys()) == [str(k) for k in g[f"state_keys__{i}"]]
+        for k, v in osd["state"][i].items():
+            ref = g[f"state__{i}__{k}"]
+            assert torch.is_tensor(v) and tuple(v.shape) == ref.shape and str(v.dtype).endswith(str(ref.dtype)), (i, k)
+    assert set(ck["scaler"].keys()) == set(json.loads(str(g["scaler_json"])).keys())
+    assert ck["epoch"] == 3

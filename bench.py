@@ -242,7 +242,7 @@ def main():
         torch.cuda.synchronize()
         gaps = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(128))
         probe_overhead_us = gaps[len(gaps) // 2]
-        epi_name = {0: "none", 1: "residual", 3: "swiglu_bwd"}
+        epi_name = {0: "none", 1: "residual", 3: "swiglu_bwd", 4: "swiglu_fwd"}
         per = {}
         for (us, fl, kind) in rec:
             if us < 0:

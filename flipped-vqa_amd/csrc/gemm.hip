@@ -235,7 +235,7 @@ int launch_skinny(const void* A, const void* B, void* C, const void* R, int M, i
 extern "C" size_t fvqa_gemm_sk_workspace(void);
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
-                      const fvqa_sk_rider* rider, int* rode);
+                      const fvqa_sk_rider* rider, int* rode, void* C2 = nullptr);
 
 extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
   (void)K; (void)dtype;
@@ -329,4 +329,20 @@ extern "C" int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const v
                         rider->ldb, rider->ldc, 0, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
   return fvqa_gemm_nt(rider->A, rider->B, rider->C, nullptr, nullptr, rider->M, rider->N, rider->K, rider->lda, rider->ldb,
                       rider->ldc, rider->M, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+}
+
+extern "C" int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K,
+                                       int lda, int ldb, int dtype, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  if (!A || !B13 || !ab || !z || !fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
+  const int N = 2 * hidden;
+  const int ke = dtype == FVQA_BF16 ? 64 : 32;
+  const size_t es = fvqa_dtype_size(dtype);
+  if (M <= 0 || hidden <= 0 || (hidden % 16) || K <= 0 || (K % ke) || lda < K || ldb < K) return FVQA_ESHAPE;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B13 & 15) || ((uintptr_t)ab & 15) || ((uintptr_t)z & 15) ||
+      ((size_t)lda * es & 15) || ((size_t)ldb * es & 15) || !workspace || ((uintptr_t)workspace & 255) ||
+      workspace_bytes < fvqa_gemm_sk_workspace())
+    return FVQA_EALIGN;
+  return fvqa_gemm_sk_impl(A, B13, ab, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, N, dtype, dtype,
+                           FVQA_EPI_SWIGLU_FWD, (hipStream_t)stream, nullptr, nullptr, z);
 }

@@ -46,6 +46,7 @@ struct SkRider {
 
 struct SkArgs {
   const void* A; const void* B; void* C; const void* R;
+  void* C2;              // FVQA_EPI_SWIGLU_FWD: z (M, N/2), row stride N/2
   float* slabs; u64* sync; u64* stamps;
   int M, N, K, lda, ldb, ldc;
   u64 epoch;
@@ -81,6 +82,9 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 #else
 #define SK_STAMP(slot) do { } while (0)
 #endif
+
+// column of a[c] in an AB16 row (W1 | W3 projections interleaved in 16-column blocks; b[c] sits 16 columns further on)
+__device__ __forceinline__ size_t ab16(int c) { return (size_t)(c >> 4) * 32 + (c & 15); }
 
 // Bounded relaxed poll of one epoch flag by the calling lane.
 __device__ __forceinline__ bool wait_epoch(u64* flag, u64 epoch, u64* err) {
@@ -125,9 +129,9 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
         qa[t] = qb[t] = uint4{0u, 0u, 0u, 0u};
         if (live(t) && m < M && nA < N) {
           if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
-            const T* rp = R + (size_t)m * ldc + nA;                   // ab rows: a | b halves, b at +ldc/2
+            const T* rp = R + (size_t)m * ldc + ab16(nA);             // ab rows (AB16): a block, b block 16 columns on
             qa[t] = *reinterpret_cast<const uint4*>(rp);
-            qb[t] = *reinterpret_cast<const uint4*>(rp + (ldc >> 1));
+            qb[t] = *reinterpret_cast<const uint4*>(rp + 16);
           } else {
             qa[t] = *reinterpret_cast<const uint4*>(R + (size_t)m * ldc + nA);
           }
@@ -156,19 +160,20 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
       float(&vA)[4] = reinterpret_cast<float(&)[4]>(v[0]);
       float(&vB)[4] = reinterpret_cast<float(&)[4]>(v[4]);
       if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
-        // v = dz[m][n..]; R = ab (rows of 2N: a | b); C = dab (rows of 2N): d(silu(a)*b)   (llama/model.py:142 backward)
+        // v = dz[m][n..]; R = ab, C = dab (rows of 2N in the AB16 layout): d(silu(a)*b)   (llama/model.py:142 backward)
         const size_t o = (size_t)m * ldc;
-        const int hb_ = ldc >> 1;
+        constexpr int hb_ = 16;                                       // b sits 16 columns after a
+        const int nA_ = (int)ab16(nA), nB_ = (int)ab16(nB);
         float a_[8], b_[8], da[8], db[8];
         if constexpr (sizeof(T) == 2) {
           if (nA >= N) continue;
           unpack8(qa[t], a_);
           unpack8(qb[t], b_);
         } else {
-          if (nA < N) { Vec4<T>::load(R + o + nA, reinterpret_cast<float(&)[4]>(a_[0]));
-                        Vec4<T>::load(R + o + hb_ + nA, reinterpret_cast<float(&)[4]>(b_[0])); }
-          if (nB < N) { Vec4<T>::load(R + o + nB, reinterpret_cast<float(&)[4]>(a_[4]));
-                        Vec4<T>::load(R + o + hb_ + nB, reinterpret_cast<float(&)[4]>(b_[4])); }
+          if (nA < N) { Vec4<T>::load(R + o + nA_, reinterpret_cast<float(&)[4]>(a_[0]));
+                        Vec4<T>::load(R + o + hb_ + nA_, reinterpret_cast<float(&)[4]>(b_[0])); }
+          if (nB < N) { Vec4<T>::load(R + o + nB_, reinterpret_cast<float(&)[4]>(a_[4]));
+                        Vec4<T>::load(R + o + hb_ + nB_, reinterpret_cast<float(&)[4]>(b_[4])); }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -177,13 +182,13 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
           db[e] = v[e] * a_[e] * sg;
         }
         if constexpr (sizeof(TO) == 2) {
-          *reinterpret_cast<uint4*>(C + o + nA) = pack8(da);
-          *reinterpret_cast<uint4*>(C + o + hb_ + nA) = pack8(db);
+          *reinterpret_cast<uint4*>(C + o + nA_) = pack8(da);
+          *reinterpret_cast<uint4*>(C + o + hb_ + nA_) = pack8(db);
         } else {
-          if (nA < N) { Vec4<TO>::store(C + o + nA, reinterpret_cast<float(&)[4]>(da[0]));
-                        Vec4<TO>::store(C + o + hb_ + nA, reinterpret_cast<float(&)[4]>(db[0])); }
-          if (nB < N) { Vec4<TO>::store(C + o + nB, reinterpret_cast<float(&)[4]>(da[4]));
-                        Vec4<TO>::store(C + o + hb_ + nB, reinterpret_cast<float(&)[4]>(db[4])); }
+          if (nA < N) { Vec4<TO>::store(C + o + nA_, reinterpret_cast<float(&)[4]>(da[0]));
+                        Vec4<TO>::store(C + o + hb_ + nA_, reinterpret_cast<float(&)[4]>(db[0])); }
+          if (nB < N) { Vec4<TO>::store(C + o + nB_, reinterpret_cast<float(&)[4]>(da[4]));
+                        Vec4<TO>::store(C + o + hb_ + nB_, reinterpret_cast<float(&)[4]>(db[4])); }
         }
       } else {
         TO* cp = C + (size_t)m * ldc;
@@ -215,6 +220,60 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
 // fetch blocks of the OWN = 8/NP row blocks this piece reduces from the NP-1 partners, add the NP partials in piece
 // order. Thanks to the row permutation (rowxor = c*OWN*16) the reduced rows are ALWAYS register blocks [0, OWN): the
 // compiler sees the published accumulators die at the stores, so all (NP-1)*OWN*4 partner loads are in flight at once.
+// FVQA_EPI_SWIGLU_FWD: the tile holds the W1 | W3 projections in the AB16 layout, so register blocks j = 0, 2 of a wave
+// are a-blocks and j = 1, 3 the matching b-blocks: z = silu(a) * b (llama/model.py:142) is formed lane by lane from the
+// values ROUNDED to the storage type (what the separate kernel reads back from `ab`), staged through the wave's LDS like
+// the tile itself and stored as 64-byte row segments: 128 rows x 32 z columns per wave.
+template <typename T>
+__device__ __forceinline__ void store_swiglu(f32x4 (&acc)[8][4], char* smem, const SkArgs& a, int m0, int n0, int w,
+                                             int lane, int n_own, int rowxor) {
+  const int wr = w >> 2, wc = w & 3;
+  const int crow = lane & 15;
+  float* stg = reinterpret_cast<float*>(smem) + w * (64 * 64);
+  T* Z = (T*)a.C2;
+  const int M = a.M, NZ = a.N >> 1;
+  const int rl = lane >> 2, ch = lane & 3;                          // row within 16, 8-column chunk of the 32
+  const int nz = (n0 >> 1) + wc * 32 + ch * 8;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (n_own <= 4 * p) continue;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int jz = 0; jz < 2; ++jz) {
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = round_to<T>(acc[p * 4 + ii][2 * jz][e]), bv = round_to<T>(acc[p * 4 + ii][2 * jz + 1][e]);
+          z[e] = round_to<T>(av / (1.f + __expf(-av))) * bv;
+        }
+        // row (ii*16 + crow) of the pass, z columns jz*16 + 4*(lane>>4) ..+3; chunk c of a row sits at c ^ (row & 7)
+        *reinterpret_cast<f32x4*>(stg + (ii * 16 + crow) * 32 + (((jz * 4 + (lane >> 4)) ^ (crow & 7)) << 2)) = z;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = t * 16 + rl;
+      const int m = m0 + wr * 128 + ((p * 64 + r) ^ rowxor);
+      float v[8];
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + r * 32 + (((2 * ch) ^ (r & 7)) << 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + r * 32 + (((2 * ch + 1) ^ (r & 7)) << 2));
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      if (4 * p + (t) >= n_own || m >= M || nz >= NZ) continue;
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(Z + (size_t)m * NZ + nz) = pack8(v);
+      } else {
+        Vec4<T>::store(Z + (size_t)m * NZ + nz, reinterpret_cast<float(&)[4]>(v[0]));
+        Vec4<T>::store(Z + (size_t)m * NZ + nz + 4, reinterpret_cast<float(&)[4]>(v[4]));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int NP>
 __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs& a, int wid, int c, int team0, int jm,
                                                 int w, int lane, int tid) {
@@ -328,7 +387,12 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
       else exchange_reduce<8>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
     }
     SK_STAMP(4);
-    store_tile<T, TO, EPI>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);
+    if constexpr (EPI == FVQA_EPI_SWIGLU_FWD) {
+      store_tile<T, TO, FVQA_EPI_NONE>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);      // ab (saved for the backward)
+      store_swiglu<T>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);                        // z
+    } else {
+      store_tile<T, TO, EPI>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);
+    }
     __syncthreads();                                      // staging reads done before the next segment's DMA
     SK_STAMP(5);
   }
@@ -401,12 +465,13 @@ extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, i
 // and the caller launches it on its own.
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
-                      const fvqa_sk_rider* rider, int* rode) {
+                      const fvqa_sk_rider* rider, int* rode, void* C2) {
   if (rode) *rode = 0;
   if (!ws || ws_bytes < fvqa_gemm_sk_workspace() || ((uintptr_t)ws & 255)) return FVQA_EALIGN;
   const int n_cu = cu_count();
   SkArgs a;
-  a.A = A; a.B = B; a.C = C; a.R = R;
+  a.A = A; a.B = B; a.C = C; a.R = R; a.C2 = C2;
+  if (epilogue == FVQA_EPI_SWIGLU_FWD && (!C2 || (N & 31) || ((uintptr_t)C2 & 15) || out_dtype != dtype)) return FVQA_EINVAL;
   a.sync = (u64*)ws;
   a.slabs = (float*)((char*)ws + SYNC_BYTES);
   a.stamps = (u64*)((char*)ws + SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float));
@@ -429,6 +494,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     case FVQA_EPI_NONE: return launch_sk<T, TO, FVQA_EPI_NONE>(a, st);                        \
     case FVQA_EPI_RESIDUAL: return launch_sk<T, TO, FVQA_EPI_RESIDUAL>(a, st);                \
     case FVQA_EPI_SWIGLU_BWD: return launch_sk<T, TO, FVQA_EPI_SWIGLU_BWD>(a, st);            \
+    case FVQA_EPI_SWIGLU_FWD: return launch_sk<T, TO, FVQA_EPI_SWIGLU_FWD>(a, st);            \
     default: return FVQA_EINVAL;                                                              \
   }
   if (dtype == FVQA_BF16) {

@@ -145,6 +145,12 @@ __global__ __launch_bounds__(256) void rope_qk_k(T* __restrict__ qkv, const floa
 }
 
 // ---- SwiGLU (reference llama/model.py:142) --------------------------------------------------
+// ab rows hold the W1 and W3 projections interleaved in 16-column blocks (include/fvqa.h "AB16"): column 32k + c is
+// a[16k + c], column 32k + 16 + c is b[16k + c] (c < 16) — the layout in which one MFMA wave of the W1|W3 GEMM holds
+// a and b of the same hidden unit in the same lane (gemm_sk.hip fuses this op into that GEMM's epilogue; these
+// kernels serve the generation path and the tests).
+__device__ __forceinline__ size_t ab16_col(int c) { return (size_t)(c >> 4) * 32 + (c & 15); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void swiglu_fwd_k(const T* __restrict__ ab, T* __restrict__ z, size_t n4,
                                                     int hidden) {
@@ -153,8 +159,8 @@ __global__ __launch_bounds__(256) void swiglu_fwd_k(const T* __restrict__ ab, T*
     const size_t r = i / h4;
     const int c = (int)(i % h4) * 4;
     float a[4], b[4], o[4];
-    Vec4<T>::load(ab + r * 2 * hidden + c, a);
-    Vec4<T>::load(ab + r * 2 * hidden + hidden + c, b);
+    Vec4<T>::load(ab + r * 2 * hidden + ab16_col(c), a);
+    Vec4<T>::load(ab + r * 2 * hidden + ab16_col(c) + 16, b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = round_to<T>(a[j] / (1.f + __expf(-a[j]))) * b[j];
     Vec4<T>::store(z + r * hidden + c, o);
@@ -169,8 +175,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const T* __restrict__ dz, co
     const size_t r = i / h4;
     const int c = (int)(i % h4) * 4;
     float a[4], b[4], g[4], da[4], db[4];
-    Vec4<T>::load(ab + r * 2 * hidden + c, a);
-    Vec4<T>::load(ab + r * 2 * hidden + hidden + c, b);
+    const size_t o = r * 2 * hidden + ab16_col(c);
+    Vec4<T>::load(ab + o, a);
+    Vec4<T>::load(ab + o + 16, b);
     Vec4<T>::load(dz + r * hidden + c, g);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -178,8 +185,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_k(const T* __restrict__ dz, co
       da[j] = g[j] * b[j] * sg * (1.f + a[j] * (1.f - sg));
       db[j] = g[j] * a[j] * sg;
     }
-    Vec4<T>::store(dab + r * 2 * hidden + c, da);
-    Vec4<T>::store(dab + r * 2 * hidden + hidden + c, db);
+    Vec4<T>::store(dab + o, da);
+    Vec4<T>::store(dab + o + 16, db);
   }
 }
 
@@ -303,7 +310,7 @@ extern "C" int fvqa_rope_qk(void* qkv, const float* cos_t, const float* sin_t, i
 extern "C" int fvqa_swiglu_fwd(const void* ab, void* z, int rows, int hidden, int dtype, void* stream) {
   if (!ab || !z) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
-  if (rows <= 0 || hidden <= 0 || hidden % 4) return FVQA_ESHAPE;
+  if (rows <= 0 || hidden <= 0 || hidden % 16) return FVQA_ESHAPE;
   const size_t n4 = (size_t)rows * (hidden / 4);
   DISPATCH_T(dtype, hipLaunchKernelGGL(swiglu_fwd_k<T>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)ab, (T*)z, n4, hidden));
@@ -315,7 +322,7 @@ extern "C" int fvqa_swiglu_bwd(const void* dz, const void* ab, void* dab, int ro
                                void* stream) {
   if (!dz || !ab || !dab) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
-  if (rows <= 0 || hidden <= 0 || hidden % 4) return FVQA_ESHAPE;
+  if (rows <= 0 || hidden <= 0 || hidden % 16) return FVQA_ESHAPE;
   const size_t n4 = (size_t)rows * (hidden / 4);
   DISPATCH_T(dtype, hipLaunchKernelGGL(swiglu_bwd_k<T>, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dz, (const T*)ab, (T*)dab, n4, hidden));

@@ -9,7 +9,7 @@
 // Sequence per layer (reference llama/model.py:184-187 with Attention :87-128, FeedForward :141-142):
 //   fwd: [xn = RMSNorm(x)] -> QKV GEMM on the sequence rows + the A adapter rows through the decode-shape kernel
 //        (their K/V projections, model.py:98-100) -> attention (RoPE inside) -> WO GEMM + residual (split-K reduced
-//        inside the launch) -> RMSNorm -> W1|W3 GEMM -> SwiGLU -> W2 GEMM + residual -> RMSNorm of the NEXT layer
+//        inside the launch) -> RMSNorm -> W1|W3 GEMM with SwiGLU in its epilogue -> W2 GEMM + residual -> RMSNorm of the NEXT layer
 //        (or the final norm)
 //   bwd: W2^T GEMM with SwiGLU' epilogue -> W1|W3^T GEMM -> RMSNorm' (+residual grad) -> WO^T GEMM -> attention'
 //        -> QKV^T GEMM on the sequence rows -> RMSNorm' (+residual grad); the adapter rows of dqkv go through the
@@ -70,9 +70,8 @@ extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p) {
   auto upd = [&](size_t v) { if (v > need) need = v; };
   upd(fvqa_gemm_workspace(R, 3 * D, D, dt));        // QKV
   upd(fvqa_gemm_workspace(R, D, D, dt));            // WO, WO^T
-  upd(fvqa_gemm_workspace(R, 2 * Hf, D, dt));       // W1|W3
+  upd(fvqa_gemm_sk_workspace());                    // W1|W3 (+SwiGLU) and W2^T (SwiGLU'): persistent kernel only
   upd(fvqa_gemm_workspace(R, D, Hf, dt));           // W2
-  upd(fvqa_gemm_sk_workspace());                    // W2^T: its SwiGLU' epilogue lives in the persistent kernel only
   upd(fvqa_gemm_workspace(R, D, 2 * Hf, dt));       // W1|W3^T
   upd(fvqa_gemm_workspace(R, D, 3 * D, dt));        // QKV^T
   return need;
@@ -116,9 +115,8 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     RUN(fvqa_gemm_nt(o, p->wo[i], h, x, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
                      p->gemm_ws_bytes, stream));
     RUN(fvqa_rmsnorm_fwd(h, p->fn[i], p->hn, p->rstd2 + (size_t)i * R, R, D, p->eps, dt, stream));
-    RUN(fvqa_gemm_nt(p->hn, p->w13[i], ab, nullptr, nullptr, R, 2 * Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_NONE, 0,
-                     p->gemm_ws, p->gemm_ws_bytes, stream));
-    RUN(fvqa_swiglu_fwd(ab, p->z, R, Hf, dt, stream));
+    // ab = hn·(W1|W3)^T and z = silu(a)*b (model.py:142) in one launch
+    RUN(fvqa_gemm_nt_swiglu_fwd(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
     // x_next = h + z·W2^T (model.py:186), then the next layer's attention norm (or the final norm)
     RUN(fvqa_gemm_nt(p->z, p->w2[i], x_next, h, nullptr, R, D, Hf, Hf, Hf, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));

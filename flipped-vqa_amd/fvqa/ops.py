@@ -196,9 +196,49 @@ def gemm_timing_read():
     return [(float(us[i]), float(fl[i]), int(kd[i])) for i in range(min(n, got))]
 
 
+def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: torch.Tensor):
+    """ab (M, 2*Hf) = x @ w13^T and z (M, Hf) = silu(a) * b in one launch; w13 / ab in the AB16 layout (pack_ab16)."""
+    _dev(x, w13, ab, z)
+    M, K = x.shape
+    N = w13.shape[0]
+    _need(w13.shape[1] == K and N % 32 == 0 and x.dtype == w13.dtype == ab.dtype == z.dtype, "gemm_nt_swiglu_fwd: operands")
+    _need(ab.shape[-1] == N and ab.numel() >= M * N and z.shape[-1] == N // 2 and z.numel() >= M * N // 2,
+          "gemm_nt_swiglu_fwd: ab / z shape")
+    lib = _lib.load()
+    ws = gemm_workspace(x.device, int(lib.fvqa_gemm_sk_workspace()))
+    timing = GEMM_TIMING
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = lib.fvqa_gemm_nt_swiglu_fwd(_ptr(x), _ptr(w13), _ptr(ab), _ptr(z), M, N // 2, K, K, K, dt_code(x.dtype),
+                                     _ptr(ws), ws.numel(), _stream())
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[x.dtype]}_{_DTN[x.dtype]}_swiglu_fwd"))
+    _lib.check(rc, "fvqa_gemm_nt_swiglu_fwd")
+    return z
+
+
+def pack_ab16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """(.., H) a and b -> (.., 2H) in the AB16 layout of include/fvqa.h: 16 columns (rows, for weights passed as
+    (H, K) matrices: use dim=0) of a, the matching 16 of b, and so on."""
+    H = a.shape[-1]
+    _need(a.shape == b.shape and H % 16 == 0, "pack_ab16: equal shapes, H % 16 == 0")
+    lead = a.shape[:-1]
+    return torch.stack([a.reshape(*lead, H // 16, 16), b.reshape(*lead, H // 16, 16)], dim=-2).reshape(*lead, 2 * H)
+
+
+def unpack_ab16(ab: torch.Tensor):
+    """inverse of pack_ab16 -> (a, b)"""
+    H2 = ab.shape[-1]
+    lead = ab.shape[:-1]
+    v = ab.reshape(*lead, H2 // 32, 2, 16)
+    return v[..., 0, :].reshape(*lead, H2 // 2), v[..., 1, :].reshape(*lead, H2 // 2)
+
+
 def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, dab: torch.Tensor):
     """dab (M, 2*Hf) = d/d(a,b)[silu(a)*b] with dz = g (M,D) @ w2_t (Hf,D)^T formed in the GEMM
-    accumulators (the SwiGLU backward is the GEMM's epilogue; dz never reaches HBM)."""
+    accumulators (the SwiGLU backward is the GEMM's epilogue; dz never reaches HBM). ab / dab: AB16 layout."""
     _dev(g, w2_t, ab, dab)
     M, K = g.shape
     N = w2_t.shape[0]

@@ -5,7 +5,7 @@ Design (MI355X-first, not a port of the reference's autograd graph):
   * the 1..3 flipped streams (vqa / vaq / qav) share every frozen weight, so they are batched
     into ONE set of n_streams*B sequences: each weight panel is read once per layer per pass and
     the projection GEMMs see M = n_streams*B*S rows (+A adapter rows that ride along);
-  * frozen weights are packed once: Wq|Wk|Wv and W1|W3 row-concatenated, plus a TRANSPOSED copy of
+  * frozen weights are packed once: Wq|Wk|Wv row-concatenated, W1|W3 row-interleaved in blocks of 16, plus a TRANSPOSED copy of
     every frozen matrix (288 GB of HBM3E makes 2x weights cheap) so that dX = dY·W is the same
     K-contiguous NT GEMM as the forward — one kernel family, no transposed LDS reads;
   * activations needed by the backward live in a preallocated arena (no allocator traffic);
@@ -44,10 +44,12 @@ class FrozenPack:
             att.wq.weight.data = wqkv[0:D]
             att.wk.weight.data = wqkv[D:2 * D]
             att.wv.weight.data = wqkv[2 * D:3 * D]
-            w13 = torch.cat([ff.w1.weight.data, ff.w3.weight.data], 0).contiguous()
-            Hf = ff.w1.weight.shape[0]
-            ff.w1.weight.data = w13[0:Hf]
-            ff.w3.weight.data = w13[Hf:2 * Hf]
+            # W1 | W3 with rows interleaved in blocks of 16 (AB16, include/fvqa.h): the GEMM that produces a and b then
+            # holds both for a hidden unit in one lane and applies SwiGLU in its epilogue. A compute copy: the module's
+            # w1 / w3 parameters keep their own storage.
+            Hf, Din = ff.w1.weight.shape
+            w13 = torch.stack([ff.w1.weight.data.view(Hf // 16, 16, Din), ff.w3.weight.data.view(Hf // 16, 16, Din)],
+                              dim=1).reshape(2 * Hf, Din).contiguous()
             self.wqkv.append(wqkv)
             self.wqkv_t.append(wqkv.t().contiguous())
             self.wo.append(att.wo.weight.data)
@@ -309,8 +311,7 @@ class StepEngine:
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
             ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)           # h = x + o·Wo^T
             ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
-            ops.gemm_nt(ar.hn, pk.w13[i], ar.ab[i])
-            ops.swiglu_fwd(ar.ab[i], ar.z, R, Hf)
+            ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z)     # ab = hn·(W1|W3)^T, z = silu(a)*b
             ops.gemm_nt(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i])   # x' = h + z·W2^T
             if i + 1 < L:
                 ops.rmsnorm_fwd(ar.xs[i + 1], pk.an[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, rows=R)

@@ -39,8 +39,13 @@ extern "C" {
 /* GEMM epilogue selector */
 #define FVQA_EPI_NONE 0
 #define FVQA_EPI_RESIDUAL 1 /* C = acc + R                                  */
-#define FVQA_EPI_SWIGLU_BWD 3 /* acc = dz (M,N): R = ab (M,2N: a|b), C = dab (M,2N) <- d/d(a,b) of
-                                silu(a)*b (llama/model.py:142 backward); ldc must be 2N     */
+#define FVQA_EPI_SWIGLU_BWD 3 /* acc = dz (M,N): R = ab (M,2N), C = dab (M,2N) <- d/d(a,b) of silu(a)*b
+                                (llama/model.py:142 backward), both in the AB16 layout below; ldc must be 2N */
+#define FVQA_EPI_SWIGLU_FWD 4 /* fvqa_gemm_nt_swiglu_fwd only: C = ab (M,N) AND z = silu(a)*b (M,N/2) */
+/* AB16: the layout of every (rows, 2*hidden) buffer that holds the W1 and W3 projections (or their gradients) side by
+ * side: column 32k + c is a[16k + c], column 32k + 16 + c is b[16k + c] (c < 16), i.e. the rows of W1 and W3 are
+ * interleaved in blocks of 16 in the packed W1|W3 matrix. One MFMA wave of the W1|W3 GEMM then holds a and b of the
+ * same hidden unit in the same lane, and SwiGLU becomes that GEMM's epilogue. hidden % 16 == 0. */
 
 int fvqa_version(void);      /* ABI version, bumped on any signature change */
 const char* fvqa_arch(void); /* "gfx950"                                     */
@@ -62,6 +67,11 @@ int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* ta
                  int M, int N, int K, int lda, int ldb, int ldc, int m_split,
                  int dtype, int out_dtype, int epilogue, int variant,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* ab[M, 2*hidden] = A[M,K] · B13[2*hidden,K]^T and z[M, hidden] = silu(a) * b in ONE launch of the persistent
+ * kernel (llama/model.py:142: w1(x), w3(x) and their product; `ab` is what the backward needs). B13 is W1|W3 with rows
+ * interleaved in blocks of 16 (AB16). Needs the fvqa_gemm_sk_workspace() workspace. */
+int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K, int lda,
+                            int ldb, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* fvqa_gemm_workspace: bytes of `workspace` the kernel variant 0 picks for the problem needs (0: none).
  * Its FIRST 4096 BYTES are the epoch flags of the persistent kernel (csrc/gemm_sk.hip): the caller zeroes them ONCE
  * after allocating the buffer (256-byte aligned); no call ever needs them reset. One workspace serves one stream at
@@ -120,7 +130,7 @@ int fvqa_rmsnorm_bwd(const void* g, const void* x, const void* w, const float* r
 int fvqa_rope_qk(void* qkv, const float* cos_t, const float* sin_t, int n_seq, int seq_len,
                  int n_heads, int head_dim, int inverse, int dtype, void* stream);
 
-/* ---- SwiGLU (llama/model.py:142). ab is (rows, 2*hidden): a = cols [0,hidden), b = rest. */
+/* ---- SwiGLU (llama/model.py:142). ab is (rows, 2*hidden) in the AB16 layout (top of this file). */
 int fvqa_swiglu_fwd(const void* ab, void* z, int rows, int hidden, int dtype, void* stream);
 /* dab (rows, 2*hidden) <- d/d(a,b) of silu(a)*b given dz (rows, hidden) */
 int fvqa_swiglu_bwd(const void* dz, const void* ab, void* dab, int rows, int hidden, int dtype,
@@ -240,11 +250,11 @@ typedef struct fvqa_layer_plan {
   /* frozen weights, per layer: fused and transposed copies (storage dtype) */
   const void* const* wqkv;   /* (3D, D)  */
   const void* const* wo;     /* (D, D)   */
-  const void* const* w13;    /* (2Hf, D) */
+  const void* const* w13;    /* (2Hf, D): W1 | W3 rows interleaved in blocks of 16 (AB16) */
   const void* const* w2;     /* (D, Hf)  */
   const void* const* wqkv_t; /* (D, 3D)  */
   const void* const* wo_t;   /* (D, D)   */
-  const void* const* w13_t;  /* (D, 2Hf) */
+  const void* const* w13_t;  /* (D, 2Hf): transpose of w13 (AB16 columns) */
   const void* const* w2_t;   /* (Hf, D)  */
   const void* const* an;     /* attention_norm weight (D) */
   const void* const* fn;     /* ffn_norm weight (D)       */
@@ -265,7 +275,7 @@ typedef struct fvqa_layer_plan {
   float* lse_a;              /* (L, n_seq*H*S) */
   float* lse_t;
   void* h;                   /* (L, R, D)   */
-  void* ab;                  /* (L, R, 2Hf) */
+  void* ab;                  /* (L, R, 2Hf), AB16 */
   void* xn;                  /* (Ra, D) scratch */
   void* hn;                  /* (R, D)  scratch */
   void* z;                   /* (R, Hf) scratch */
@@ -278,7 +288,7 @@ typedef struct fvqa_layer_plan {
   void* dcur;                /* (R, D) */
   void* dnxt;                /* (R, D) */
   void* dz;                  /* (R, max(Hf, D)) scratch */
-  void* dab;                 /* (R, 2Hf) */
+  void* dab;                 /* (R, 2Hf), AB16 */
   void* dh;                  /* (R, D) */
   void* d_o;                 /* (R, D) */
   void* dqkv;                /* (Ra, 3D) */

@@ -138,13 +138,40 @@ def test_gemm_nt_swiglu_bwd_epilogue(dtype, M, Hf, D):
     if dtype == torch.float32 and M > 1024:
         pytest.skip("fp32 covered by the small shapes")
     g, w2t = rnd(M, D, dtype=dtype, seed=41), rnd(Hf, D, dtype=dtype, scale=1 / math.sqrt(D), seed=42)
-    ab = rnd(M, 2 * Hf, dtype=dtype, scale=3, seed=43)
+    a, b = rnd(M, Hf, dtype=dtype, scale=3, seed=43), rnd(M, Hf, dtype=dtype, scale=3, seed=44)
     dab = torch.empty(M, 2 * Hf, dtype=dtype, device=DEV)
-    ops.gemm_nt_swiglu_bwd(dev(g), dev(w2t), dev(ab), dab)
+    ops.gemm_nt_swiglu_bwd(dev(g), dev(w2t), dev(ops.pack_ab16(a, b)), dab)
     dz = g.double() @ w2t.double().T
-    da, db = ref_cpu.swiglu_bwd(dz, ab[:, :Hf].double(), ab[:, Hf:].double())
-    assert rel(dab[:, :Hf], da) < tol(dtype, 5e-5, 1e-2)
-    assert rel(dab[:, Hf:], db) < tol(dtype, 5e-5, 1e-2)
+    da, db = ref_cpu.swiglu_bwd(dz, a.double(), b.double())
+    ga, gb = ops.unpack_ab16(dab)
+    assert rel(ga, da) < tol(dtype, 5e-5, 1e-2)
+    assert rel(gb, db) < tol(dtype, 5e-5, 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Hf,D", [(74, 768, 256), (1024, 1536, 512), (1024, 11008, 1024), (3072, 2816, 512),
+                                    (1024, 144, 4096)])
+def test_gemm_nt_swiglu_fwd_epilogue(dtype, M, Hf, D):
+    """ab = x·(W1|W3)^T and z = silu(a)*b from ONE launch (llama/model.py:142), W1|W3 rows interleaved in 16-blocks:
+    against the fp64 products, and z bitwise equal to the separate SwiGLU kernel run on the stored ab (the epilogue
+    forms z from the ROUNDED a, b). Shapes: whole tiles, a split last round (Hf = 11008 at K = 1024), m groups, and a
+    split-K tile set (Hf = 144: 2 n tiles x 4 pieces)."""
+    if dtype == torch.float32 and M * Hf * D > 2 ** 32:
+        pytest.skip("fp32 covered by the smaller shapes")
+    x = rnd(M, D, dtype=dtype, seed=45)
+    w1, w3 = rnd(Hf, D, dtype=dtype, scale=2 / math.sqrt(D), seed=46), rnd(Hf, D, dtype=dtype, scale=2 / math.sqrt(D), seed=47)
+    w13 = ops.pack_ab16(w1.T.contiguous(), w3.T.contiguous()).T.contiguous()        # rows interleaved in 16-blocks
+    assert torch.equal(w13[0:16], w1[0:16]) and torch.equal(w13[16:32], w3[0:16])
+    ab = torch.empty(M, 2 * Hf, dtype=dtype, device=DEV)
+    z = torch.empty(M, Hf, dtype=dtype, device=DEV)
+    ops.gemm_nt_swiglu_fwd(dev(x), dev(w13), ab, z)
+    a_ref, b_ref = x.double() @ w1.double().T, x.double() @ w3.double().T
+    ga, gb = ops.unpack_ab16(ab)
+    assert rel(ga, a_ref) < tol(dtype, 5e-5, 1e-2) and rel(gb, b_ref) < tol(dtype, 5e-5, 1e-2)
+    assert rel(z, ref_cpu.silu(a_ref) * b_ref) < tol(dtype, 5e-5, 2e-2)
+    z2 = torch.empty_like(z)
+    ops.swiglu_fwd(ab, z2, M, Hf)
+    assert torch.equal(z, z2)
 
 
 @pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (1, 520, 256), (16, 1000, 2816), (3, 22016, 1024)])
@@ -256,17 +283,24 @@ def test_rope(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_swiglu(dtype):
+    """(rows, 2*hidden) buffers are in the AB16 layout (include/fvqa.h): ops.pack_ab16 / unpack_ab16."""
     rows, hidden = 37, 768
-    ab, dz = rnd(rows, 2 * hidden, dtype=dtype, scale=3, seed=1), rnd(rows, hidden, dtype=dtype, seed=2)
+    a, b = rnd(rows, hidden, dtype=dtype, scale=3, seed=1), rnd(rows, hidden, dtype=dtype, scale=3, seed=3)
+    dz = rnd(rows, hidden, dtype=dtype, seed=2)
+    ab = ops.pack_ab16(a, b)
+    assert torch.equal(ab[:, 0:16], a[:, 0:16]) and torch.equal(ab[:, 16:32], b[:, 0:16]) and \
+        torch.equal(ab[:, 32:48], a[:, 16:32])
+    ua, ub = ops.unpack_ab16(ab)
+    assert torch.equal(ua, a) and torch.equal(ub, b)
     z = torch.empty(rows, hidden, dtype=dtype, device=DEV)
     ops.swiglu_fwd(dev(ab), z, rows, hidden)
-    a, b = ab[:, :hidden].double(), ab[:, hidden:].double()
-    assert rel(z, ref_cpu.silu(a) * b) < tol(dtype)
+    assert rel(z, ref_cpu.silu(a.double()) * b.double()) < tol(dtype)
     dab = torch.empty(rows, 2 * hidden, dtype=dtype, device=DEV)
     ops.swiglu_bwd(dev(dz), dev(ab), dab, rows, hidden)
-    da, db = ref_cpu.swiglu_bwd(dz.double(), a, b)
-    assert rel(dab[:, :hidden], da) < tol(dtype)
-    assert rel(dab[:, hidden:], db) < tol(dtype)
+    da, db = ref_cpu.swiglu_bwd(dz.double(), a.double(), b.double())
+    ga, gb = ops.unpack_ab16(dab)
+    assert rel(ga, da) < tol(dtype)
+    assert rel(gb, db) < tol(dtype)
 
 
 # ------------------------------------------------------------------------------ attention

@@ -235,7 +235,7 @@ int launch_skinny(const void* A, const void* B, void* C, const void* R, int M, i
 extern "C" size_t fvqa_gemm_sk_workspace(void);
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
-                      const fvqa_sk_rider* rider, int* rode, void* C2 = nullptr, const fvqa_gemm_opts* opts = nullptr);
+                      const fvqa_sk_rider* rider, int* rode, void* C2 = nullptr);
 
 extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
   (void)K; (void)dtype;
@@ -345,35 +345,4 @@ extern "C" int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab,
     return FVQA_EALIGN;
   return fvqa_gemm_sk_impl(A, B13, ab, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, N, dtype, dtype,
                            FVQA_EPI_SWIGLU_FWD, (hipStream_t)stream, nullptr, nullptr, z);
-}
-
-// The persistent kernel with every option of fvqa_gemm_opts (include/fvqa.h): the form the layer schedule uses.
-extern "C" int fvqa_gemm_nt_ex(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
-                               int ldb, int ldc, int dtype, int out_dtype, int epilogue, const fvqa_gemm_opts* opts,
-                               void* workspace, size_t workspace_bytes, void* stream) {
-  if (!A || !B || !C || !fvqa_dtype_ok(dtype) || !fvqa_dtype_ok(out_dtype)) return FVQA_EINVAL;
-  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_SWIGLU_BWD &&
-      epilogue != FVQA_EPI_SWIGLU_FWD)
-    return FVQA_EINVAL;
-  if ((epilogue == FVQA_EPI_RESIDUAL || epilogue == FVQA_EPI_SWIGLU_BWD) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
-  if (epilogue == FVQA_EPI_SWIGLU_BWD && ldc != 2 * N) return FVQA_EINVAL;
-  if (epilogue == FVQA_EPI_SWIGLU_FWD && (!opts || !opts->z)) return FVQA_EINVAL;
-  if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
-  const int ke = dtype == FVQA_BF16 ? 64 : 32;
-  const size_t es = fvqa_dtype_size(dtype);
-  if (M <= 0 || N <= 0 || K <= 0 || (K % ke) || lda < K || ldb < K || ldc < N || (N & 7) || (ldc & 7)) return FVQA_ESHAPE;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((size_t)lda * es & 15) || ((size_t)ldb * es & 15) ||
-      (((uintptr_t)C | (uintptr_t)R) & 15) || !workspace || ((uintptr_t)workspace & 255) ||
-      workspace_bytes < fvqa_gemm_sk_workspace())
-    return FVQA_EALIGN;
-  const fvqa_sk_rider* rider = opts ? opts->rider : nullptr;
-  int rode = 0;
-  int rc = fvqa_gemm_sk_impl(A, B, C, R, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, dtype, out_dtype, epilogue,
-                             (hipStream_t)stream, rider, &rode, opts ? opts->z : nullptr, opts);
-  if (rc || !rider || rode) return rc;
-  if (rider->accumulate_f32)
-    return fvqa_gemm_nt(rider->A, rider->B, nullptr, nullptr, (float*)rider->C, rider->M, rider->N, rider->K, rider->lda,
-                        rider->ldb, rider->ldc, 0, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
-  return fvqa_gemm_nt(rider->A, rider->B, rider->C, nullptr, nullptr, rider->M, rider->N, rider->K, rider->lda, rider->ldb,
-                      rider->ldc, rider->M, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
 }

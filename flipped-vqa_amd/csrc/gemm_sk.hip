@@ -47,11 +47,6 @@ struct SkRider {
 struct SkArgs {
   const void* A; const void* B; void* C; const void* R;
   void* C2;              // FVQA_EPI_SWIGLU_FWD: z (M, N/2), row stride N/2
-  // RMSNorm of A folded into the product (the norm weight is already folded into B's columns by the host): every output
-  // row m is scaled by rstd[m] = rsqrt(sum_p ssq_in[m][p] / K + eps) (n_ssq_in > 0: partial row sums of squares left by
-  // the launch that wrote A) or by rstd_in[m] (n_ssq_in == 0). rstd_out (may be NULL) receives rstd for the backward.
-  const float* ssq_in; const float* rstd_in; float* rstd_out; int n_ssq_in; float eps;
-  float* ssq_out;        // per-row partial sums of squares of the STORED output, (M, 4 * tn): [m][4 * n_tile + wave column]
   float* slabs; u64* sync; u64* stamps;
   int M, N, K, lda, ldb, ldc;
   u64 epoch;
@@ -214,19 +209,6 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
           if (nA < N) Vec4<TO>::store(cp + nA, vA);
           if (nB < N) Vec4<TO>::store(cp + nB, vB);
         }
-        if (a.ssq_out != nullptr) {        // the 8 lanes of a row hold this wave's 64 columns of it (all take this branch)
-          float ss = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const bool in = (sizeof(TO) == 2 || e < 4) ? nA < N : nB < N;
-            const float x = in ? round_to<TO>(v[e]) : 0.f;
-            ss += x * x;
-          }
-          ss += __shfl_xor(ss, 1, 64);
-          ss += __shfl_xor(ss, 2, 64);
-          ss += __shfl_xor(ss, 4, 64);
-          if (k == 0) a.ssq_out[(size_t)m * (4 * a.plan.tn) + (n0 >> 6) + wc] = ss;
-        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -384,28 +366,6 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
     const int own = 8 / s.n;                              // register blocks this piece reduces and stores
     const int rowxor = s.n > 1 ? s.c * own * 16 : 0;
 
-    // folded RMSNorm: thread t < 256 works out rstd of tile row t while the ring fills (the partial sums were left by
-    // the launch that wrote A) and carries it across the loop in one register
-    const bool normed = a.ssq_in != nullptr || a.rstd_in != nullptr;
-    float my_rstd = 1.f;
-    if (normed && tid < 256) {
-      const int m = m0 + tid;
-      if (m < a.M) {
-        if (a.n_ssq_in > 0) {
-          float ss = 0.f;
-          const float* sp = a.ssq_in + (size_t)m * a.n_ssq_in;
-          for (int p = 0; p < a.n_ssq_in; p += 4) {
-            const float4 q4 = *reinterpret_cast<const float4*>(sp + p);
-            ss += q4.x; ss += q4.y; ss += q4.z; ss += q4.w;
-          }
-          my_rstd = rsqrtf(ss / (float)a.K + a.eps);
-          if (a.rstd_out != nullptr && tni == 0) a.rstd_out[m] = my_rstd;
-        } else {
-          my_rstd = a.rstd_in[m];
-        }
-      }
-    }
-
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -427,19 +387,6 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
       else exchange_reduce<8>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
     }
     SK_STAMP(4);
-    if (normed) {                                         // scale the rows: acc[i][*] of a lane is tile row (wr*128 + i*16 + lane%16) ^ rowxor
-      float* rs = reinterpret_cast<float*>(smem + 8 * 64 * 64 * 4);     // behind the 8 waves' staging areas
-      asm volatile("" : "+v"(my_rstd));
-      if (tid_e < 256) rs[tid_e] = my_rstd;
-      __syncthreads();
-      const int rbase = (w_e >> 2) * 128 + (lane_e & 15);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float sc = rs[(rbase + i * 16) ^ rowxor];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] *= sc;
-      }
-    }
     if constexpr (EPI == FVQA_EPI_SWIGLU_FWD) {
       store_tile<T, TO, FVQA_EPI_NONE>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);      // ab (saved for the backward)
       store_swiglu<T>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);                        // z
@@ -518,21 +465,13 @@ extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, i
 // and the caller launches it on its own.
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
-                      const fvqa_sk_rider* rider, int* rode, void* C2, const fvqa_gemm_opts* opts) {
+                      const fvqa_sk_rider* rider, int* rode, void* C2) {
   if (rode) *rode = 0;
   if (!ws || ws_bytes < fvqa_gemm_sk_workspace() || ((uintptr_t)ws & 255)) return FVQA_EALIGN;
   const int n_cu = cu_count();
   SkArgs a;
   a.A = A; a.B = B; a.C = C; a.R = R; a.C2 = C2;
   if (epilogue == FVQA_EPI_SWIGLU_FWD && (!C2 || (N & 31) || ((uintptr_t)C2 & 15) || out_dtype != dtype)) return FVQA_EINVAL;
-  a.ssq_in = nullptr; a.rstd_in = nullptr; a.rstd_out = nullptr; a.n_ssq_in = 0; a.eps = 0.f; a.ssq_out = nullptr;
-  if (opts) {
-    if (opts->n_ssq_in < 0 || (opts->n_ssq_in & 3) || (opts->n_ssq_in > 0 && !opts->ssq_in)) return FVQA_EINVAL;
-    if (opts->ssq_out && epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL) return FVQA_EINVAL;
-    a.ssq_in = opts->n_ssq_in > 0 ? opts->ssq_in : nullptr;
-    a.rstd_in = opts->n_ssq_in > 0 ? nullptr : opts->rstd_in;
-    a.rstd_out = opts->rstd_out; a.n_ssq_in = opts->n_ssq_in; a.eps = opts->eps; a.ssq_out = opts->ssq_out;
-  }
   a.sync = (u64*)ws;
   a.slabs = (float*)((char*)ws + SYNC_BYTES);
   a.stamps = (u64*)((char*)ws + SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float));

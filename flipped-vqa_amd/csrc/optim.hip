@@ -129,5 +129,5 @@ extern "C" int fvqa_scaler_update(float* step, float* scale, float* growth_track
   return FVQA_OK;
 }
 
-extern "C" int fvqa_version(void) { return 10; }
+extern "C" int fvqa_version(void) { return 9; }
 extern "C" const char* fvqa_arch(void) { return "gfx950"; }

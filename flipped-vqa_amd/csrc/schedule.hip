@@ -7,11 +7,10 @@
 // launch stream no longer depends on the speed of the Python interpreter.
 //
 // Sequence per layer (reference llama/model.py:184-187 with Attention :87-128, FeedForward :141-142):
-//   fwd: QKV GEMM with the attention RMSNorm folded in (norm weight in the packed weights, rstd row scale in the
-//        epilogue; the A adapter rows get their K/V projections, model.py:98-100, on the launch's idle CUs) -> attention
-//        (RoPE inside) -> WO GEMM + residual (split-K reduced inside the launch; leaves row sums of squares) -> W1|W3
-//        GEMM with the ffn RMSNorm folded in and SwiGLU in its epilogue -> W2 GEMM + residual (leaves row sums of squares
-//        for the next layer); only layer 0's rstd and the final norm are row kernels
+//   fwd: [xn = RMSNorm(x)] -> QKV GEMM on the sequence rows + the A adapter rows through the decode-shape kernel
+//        (their K/V projections, model.py:98-100) -> attention (RoPE inside) -> WO GEMM + residual (split-K reduced
+//        inside the launch) -> RMSNorm -> W1|W3 GEMM with SwiGLU in its epilogue -> W2 GEMM + residual -> RMSNorm of the NEXT layer
+//        (or the final norm)
 //   bwd: W2^T GEMM with SwiGLU' epilogue -> W1|W3^T GEMM -> RMSNorm' (+residual grad) -> WO^T GEMM -> attention'
 //        -> QKV^T GEMM on the sequence rows -> RMSNorm' (+residual grad); the adapter rows of dqkv go through the
 //        decode-shape kernel straight into the fp32 adapter-query gradient (+=)
@@ -45,7 +44,7 @@ int check_plan(const fvqa_layer_plan* p) {
   if (p->gemm_ws_bytes < fvqa_layers_gemm_workspace(p)) return FVQA_EALIGN;
   if (!p->wqkv || !p->wo || !p->w13 || !p->w2 || !p->wqkv_t || !p->wo_t || !p->w13_t || !p->w2_t || !p->an ||
       !p->fn || !p->gate1 || !p->gate2 || !p->adapter || !p->norm_w || !p->xs || !p->rstd1 || !p->rstd2 || !p->qkv ||
-      !p->o || !p->lse_a || !p->lse_t || !p->h || !p->ab || !p->xn || !p->z || !p->xnf || !p->rstdN ||
+      !p->o || !p->lse_a || !p->lse_t || !p->h || !p->ab || !p->xn || !p->hn || !p->z || !p->xnf || !p->rstdN ||
       !p->cos_t || !p->sin_t || !p->vstart || !p->gemm_ws)
     return FVQA_EINVAL;
   if ((uintptr_t)p->gemm_ws & 255) return FVQA_EALIGN;
@@ -85,13 +84,9 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
   const int R = n_seq * S, Ra = R + A;
   const size_t es = fvqa_dtype_size(dt);
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
-  if (!p->adapter_c || !p->wqkv_s || !p->w13_s || !p->ssq_x || !p->ssq_h) return FVQA_EINVAL;
-  const int n_ssq = 4 * ((D + 255) / 256);             // partial row sums of squares per row of a (R, D) output
+  if (!p->adapter_c) return FVQA_EINVAL;
   // the adapter prompts of all walked layers in storage dtype (model.py:339 `.half()`), one launch
   RUN(fvqa_cast_rows(p->adapter, p->adapter_c, L * A, D, dt, stream));
-  // layer 0's input comes from the embedding gather: its rstd from the norm kernel; every later RMSNorm is folded
-  // into the projection that consumes it (norm weight pre-multiplied into wqkv_s / w13_s, row scale rstd in the
-  // epilogue from the partial sums of squares the producing projection left)
   RUN(fvqa_rmsnorm_fwd(p->xs, p->an[0], p->xn, p->rstd1, R, D, p->eps, dt, stream));
   for (int i = 0; i < L; ++i) {
     const void* x = at(p->xs, (size_t)i * R * D, es);
@@ -102,14 +97,12 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
     float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
     float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
-    // q,k,v = RMSNorm(x)·Wqkv^T (model.py:185 -> :89). Rider: the A adapter rows under the sequence rows of qkv get their
-    // K and V projections (model.py:98-100: no norm, plain Wk / Wv; their q block is never read) on the idle CUs
+    // the A adapter rows under the sequence rows of qkv get their K and V projections (model.py:98-100; their q block
+    // is never read) on the CUs the QKV GEMM leaves idle
     const fvqa_sk_rider kv = {at(p->adapter_c, (size_t)i * A * D, es), at(p->wqkv[i], (size_t)D * D, es),
                               at(qkv, (size_t)R * 3 * D + D, es), A, 2 * D, D, D, D, 3 * D, 0};
-    fvqa_gemm_opts oq = {&kv, nullptr, i ? p->ssq_x : nullptr, i ? nullptr : p->rstd1, i ? p->rstd1 + (size_t)i * R : nullptr,
-                         nullptr, i ? n_ssq : 0, p->eps};
-    RUN(fvqa_gemm_nt_ex(x, p->wqkv_s[i], qkv, nullptr, R, 3 * D, D, D, D, 3 * D, dt, dt, FVQA_EPI_NONE, &oq, p->gemm_ws,
-                        p->gemm_ws_bytes, stream));
+    RUN(fvqa_gemm_nt_rider(p->xn, p->wqkv[i], qkv, nullptr, R, 3 * D, D, D, D, 3 * D, dt, dt, FVQA_EPI_NONE, &kv,
+                           p->gemm_ws, p->gemm_ws_bytes, stream));
     if (fused_rope) {                                  // bf16 MFMA build: q,k stay raw and are rotated inside
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t, n_seq, S, H, Dh,
                         A, p->max_feats, dt, stream));
@@ -118,21 +111,20 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, nullptr, nullptr, n_seq, S, H, Dh, A,
                         p->max_feats, dt, stream));
     }
-    // h = x + o·Wo^T (model.py:185); leaves the row sums of squares of h for the ffn norm
-    fvqa_gemm_opts oo = {nullptr, nullptr, nullptr, nullptr, nullptr, p->ssq_h, 0, 0.f};
-    RUN(fvqa_gemm_nt_ex(o, p->wo[i], h, x, R, D, D, D, D, D, dt, dt, FVQA_EPI_RESIDUAL, &oo, p->gemm_ws, p->gemm_ws_bytes,
-                        stream));
-    // ab = RMSNorm(h)·(W1|W3)^T and z = silu(a)*b (model.py:186 -> :142) in one launch
-    fvqa_gemm_opts o13 = {nullptr, p->z, p->ssq_h, nullptr, p->rstd2 + (size_t)i * R, nullptr, n_ssq, p->eps};
-    RUN(fvqa_gemm_nt_ex(h, p->w13_s[i], ab, nullptr, R, 2 * Hf, D, D, D, 2 * Hf, dt, dt, FVQA_EPI_SWIGLU_FWD, &o13,
-                        p->gemm_ws, p->gemm_ws_bytes, stream));
-    // x' = h + z·W2^T (model.py:186); leaves the row sums of squares of x' for the next layer's attention norm
-    fvqa_gemm_opts o2 = {nullptr, nullptr, nullptr, nullptr, nullptr, p->ssq_x, 0, 0.f};
-    RUN(fvqa_gemm_nt_ex(p->z, p->w2[i], x_next, h, R, D, Hf, Hf, Hf, D, dt, dt, FVQA_EPI_RESIDUAL, &o2, p->gemm_ws,
-                        p->gemm_ws_bytes, stream));
+    // h = x + o·Wo^T (model.py:185), hn = RMSNorm(h)·w
+    RUN(fvqa_gemm_nt(o, p->wo[i], h, x, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
+                     p->gemm_ws_bytes, stream));
+    RUN(fvqa_rmsnorm_fwd(h, p->fn[i], p->hn, p->rstd2 + (size_t)i * R, R, D, p->eps, dt, stream));
+    // ab = hn·(W1|W3)^T and z = silu(a)*b (model.py:142) in one launch
+    RUN(fvqa_gemm_nt_swiglu_fwd(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
+    // x_next = h + z·W2^T (model.py:186), then the next layer's attention norm (or the final norm)
+    RUN(fvqa_gemm_nt(p->z, p->w2[i], x_next, h, nullptr, R, D, Hf, Hf, Hf, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0,
+                     p->gemm_ws, p->gemm_ws_bytes, stream));
+    if (i + 1 < L)
+      RUN(fvqa_rmsnorm_fwd(x_next, p->an[i + 1], p->xn, p->rstd1 + (size_t)(i + 1) * R, R, D, p->eps, dt, stream));
+    else
+      RUN(fvqa_rmsnorm_fwd(x_next, p->norm_w, p->xnf, p->rstdN, R, D, p->eps, dt, stream));
   }
-  // the final norm is materialised: the LM head and the QAV head both read it
-  RUN(fvqa_rmsnorm_fwd(at(p->xs, (size_t)L * R * D, es), p->norm_w, p->xnf, p->rstdN, R, D, p->eps, dt, stream));
   return FVQA_OK;
 }
 

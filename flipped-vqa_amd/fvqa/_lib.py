@@ -11,8 +11,8 @@ import os
 from typing import Optional
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_FWD = 0, 1, 3, 4
-ABI_VERSION = 10
+EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD = 0, 1, 3
+ABI_VERSION = 9
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -23,7 +23,6 @@ SIGNATURES = {
     "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
     "fvqa_gemm_sk_workspace": (_sz, []),
-    "fvqa_gemm_nt_ex": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "fvqa_gemm_nt_swiglu_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "fvqa_gemm_nt_rider": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "fvqa_gemm_sk_describe": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i]),
@@ -59,12 +58,6 @@ SIGNATURES = {
 _pp = C.POINTER(C.c_void_p)
 
 
-class GemmOpts(C.Structure):
-    """Mirror of `fvqa_gemm_opts` (include/fvqa.h)."""
-    _fields_ = [("rider", C.c_void_p), ("z", C.c_void_p), ("ssq_in", C.c_void_p), ("rstd_in", C.c_void_p),
-                ("rstd_out", C.c_void_p), ("ssq_out", C.c_void_p), ("n_ssq_in", C.c_int32), ("eps", C.c_float)]
-
-
 class SkRider(C.Structure):
     """Mirror of `fvqa_sk_rider` (include/fvqa.h)."""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p)] + \
@@ -77,11 +70,10 @@ class LayerPlan(C.Structure):
         [(n, C.c_int32) for n in ("dtype", "n_layers", "n_seq", "seq_len", "n_heads", "head_dim", "adapter_len",
                                   "max_feats", "dim", "hidden")]
         + [("eps", C.c_float), ("reserved_", C.c_int32)]
-        + [(n, _pp) for n in ("wqkv", "wo", "w13", "w2", "wqkv_s", "w13_s", "wqkv_t", "wo_t", "w13_t", "w2_t", "an", "fn",
-                              "gate1",
+        + [(n, _pp) for n in ("wqkv", "wo", "w13", "w2", "wqkv_t", "wo_t", "w13_t", "w2_t", "an", "fn", "gate1",
                               "gate2", "dgate1", "dgate2")]
         + [(n, C.c_void_p) for n in ("adapter", "adapter_c", "d_adapter", "norm_w", "xs", "rstd1", "rstd2", "qkv", "o", "lse_a",
-                                     "lse_t", "h", "ab", "xn", "ssq_x", "ssq_h", "z", "xnf", "rstdN", "cos_t", "sin_t",
+                                     "lse_t", "h", "ab", "xn", "hn", "z", "xnf", "rstdN", "cos_t", "sin_t",
                                      "vstart", "dcur", "dnxt", "dz", "dab", "dh", "d_o", "dqkv", "attn_ws")]
         + [("attn_ws_bytes", C.c_size_t), ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t)]
     )

@@ -130,74 +130,6 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
     return out
 
 
-def gemm_nt_ex(a, b, out, *, residual=None, swiglu_z=None, swiglu_ab=None, rider=None, ssq_in=None, rstd_in=None,
-               rstd_out=None, eps: float = 0.0, ssq_out=None):
-    """fvqa_gemm_nt_ex: out = epilogue(a @ b^T) on the persistent kernel with the options of fvqa_gemm_opts —
-    residual add | SwiGLU forward (out = ab, swiglu_z = z) | SwiGLU' (swiglu_ab given, out = dab); rider =
-    (A2, B2, C2, accumulate); RMSNorm of `a` folded in (ssq_in (M, n) partial row sums of squares or rstd_in (M), eps,
-    rstd_out); ssq_out (M, 4*ceil(N/256)) partial row sums of squares of the stored output."""
-    import ctypes as C
-    _dev(a, b, out, residual, swiglu_ab, rows_strided=True)
-    _dev(swiglu_z, ssq_in, rstd_in, rstd_out, ssq_out)
-    M, K = a.shape
-    Nb = b.shape[0]
-    _need(b.shape[1] == K and a.dtype == b.dtype, "gemm_nt_ex: operands")
-    epi, R, N = EPI_NONE, None, Nb
-    if swiglu_ab is not None:
-        _need(tuple(out.shape) == (M, 2 * Nb) and swiglu_ab.shape == out.shape, "gemm_nt_ex: SwiGLU' operands")
-        epi, R = EPI_SWIGLU_BWD, swiglu_ab
-    elif swiglu_z is not None:
-        _need(tuple(out.shape) == (M, Nb) and Nb % 32 == 0 and swiglu_z.numel() >= M * Nb // 2 and
-              swiglu_z.dtype == a.dtype, "gemm_nt_ex: SwiGLU operands")
-        epi = _lib.EPI_SWIGLU_FWD
-    else:
-        _need(tuple(out.shape) == (M, Nb), "gemm_nt_ex: out shape")
-        if residual is not None:
-            _need(residual.shape == out.shape and residual.stride(0) == out.stride(0), "gemm_nt_ex: residual")
-            epi, R = EPI_RESIDUAL, residual
-    opts = _lib.GemmOpts()
-    keep = None
-    if rider is not None:
-        ra, rb, rc_, acc = rider
-        _dev(ra, rb, rows_strided=True)
-        _need(ra.shape[1] == rb.shape[1] and tuple(rc_.shape) == (ra.shape[0], rb.shape[0]) and ra.shape[0] <= 16 and
-              rc_.stride(1) == 1 and (not acc or (rc_.dtype == torch.float32 and rc_.stride(0) == rb.shape[0])),
-              "gemm_nt_ex: rider")
-        keep = _lib.SkRider(ra.data_ptr(), rb.data_ptr(), rc_.data_ptr(), ra.shape[0], rb.shape[0], ra.shape[1],
-                            ra.stride(0), rb.stride(0), rc_.stride(0), 1 if acc else 0)
-        opts.rider = C.addressof(keep)
-    opts.z = _ptr(swiglu_z)
-    if ssq_in is not None:
-        _need(ssq_in.dtype == torch.float32 and ssq_in.dim() == 2 and ssq_in.shape[0] >= M and ssq_in.shape[1] % 4 == 0,
-              "gemm_nt_ex: ssq_in")
-        opts.ssq_in, opts.n_ssq_in = _ptr(ssq_in), ssq_in.shape[1]
-    if rstd_in is not None:
-        _need(ssq_in is None and rstd_in.dtype == torch.float32 and rstd_in.numel() >= M, "gemm_nt_ex: rstd_in")
-        opts.rstd_in = _ptr(rstd_in)
-    if rstd_out is not None:
-        _need(rstd_out.dtype == torch.float32 and rstd_out.numel() >= M, "gemm_nt_ex: rstd_out")
-        opts.rstd_out = _ptr(rstd_out)
-    if ssq_out is not None:
-        _need(ssq_out.dtype == torch.float32 and tuple(ssq_out.shape) == (M, 4 * ((N + 255) // 256)) and
-              epi in (EPI_NONE, EPI_RESIDUAL), "gemm_nt_ex: ssq_out")
-        opts.ssq_out = _ptr(ssq_out)
-    opts.eps = float(eps)
-    lib = _lib.load()
-    ws = gemm_workspace(a.device, int(lib.fvqa_gemm_sk_workspace()))
-    timing = GEMM_TIMING
-    if timing is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    rc = lib.fvqa_gemm_nt_ex(_ptr(a), _ptr(b), _ptr(out), _ptr(R), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-                             dt_code(a.dtype), dt_code(out.dtype), epi, C.addressof(opts), _ptr(ws), ws.numel(),
-                             _stream())
-    if timing is not None:
-        e1.record()
-        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_ex{epi}"))
-    _lib.check(rc, "fvqa_gemm_nt_ex")
-    return out
-
-
 def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = False, residual=None, swiglu_ab=None):
     """out = a @ b^T (+ residual | SwiGLU' epilogue with swiglu_ab) and, on the CUs that launch leaves idle (or right
     after it), the small product rider_out (<= 16 rows) = rider_a @ rider_b^T (accumulate: fp32 rider_out += product).

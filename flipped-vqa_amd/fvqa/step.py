@@ -33,7 +33,6 @@ class FrozenPack:
         self.layer_ids = layer_ids
         self.wqkv, self.wqkv_t, self.wo, self.wo_t = [], [], [], []
         self.w13, self.w13_t, self.w2, self.w2_t = [], [], [], []
-        self.wqkv_s, self.w13_s = [], []        # forward copies with the RMSNorm weight folded into their columns
         self.an, self.fn = [], []
         for li in layer_ids:
             blk = model.layers[li]
@@ -53,10 +52,6 @@ class FrozenPack:
                               dim=1).reshape(2 * Hf, Din).contiguous()
             self.wqkv.append(wqkv)
             self.wqkv_t.append(wqkv.t().contiguous())
-            # RMSNorm(x)·W^T = rstd ⊙ (x · (W·diag(w))^T): the frozen norm weight goes into the frozen projection once
-            # (fp32 product, rounded to the storage type), rstd is a row scale in the GEMM epilogue
-            self.wqkv_s.append((wqkv.float() * blk.attention_norm.weight.data.float()[None, :]).to(dt))
-            self.w13_s.append((w13.float() * blk.ffn_norm.weight.data.float()[None, :]).to(dt))
             self.wo.append(att.wo.weight.data)
             self.wo_t.append(att.wo.weight.data.t().contiguous())
             self.w13.append(w13)
@@ -94,10 +89,8 @@ class Arena:
         self.h = e(L, R, D)
         self.ab = e(L, R, 2 * Hf)
         self.xn = e(R, D)
-        n_ssq = 4 * ((D + 255) // 256)
-        self.ssq_x = e(R, n_ssq, dtype=f32)     # partial row sums of squares left by the W2 / WO projections
-        self.ssq_h = e(R, n_ssq, dtype=f32)
         self.adapter_c = e(L, A, D)             # storage-dtype cast of the walked layers' adapter prompts
+        self.hn = e(R, D)
         self.z = e(R, Hf)
         self.xnf = e(R, D)
         self.rstdN = e(R, dtype=f32)
@@ -181,7 +174,7 @@ class StepEngine:
             keep.append((arr, tensors))
             return C.cast(arr, C.POINTER(C.c_void_p))
 
-        for name in ("wqkv", "wo", "w13", "w2", "wqkv_s", "w13_s", "wqkv_t", "wo_t", "w13_t", "w2_t", "an", "fn"):
+        for name in ("wqkv", "wo", "w13", "w2", "wqkv_t", "wo_t", "w13_t", "w2_t", "an", "fn"):
             setattr(plan, name, table(getattr(pk, name)))
         gv = [m.gate_views(i) for i in range(L)]
         gg = [grads.gate_grad_views(i) for i in range(L)]
@@ -191,8 +184,7 @@ class StepEngine:
         plan.adapter_c = ar.adapter_c.data_ptr()
         plan.d_adapter = grads.grad_view("adapter_query.weight").data_ptr()
         plan.norm_w = pk.norm.data_ptr()
-        for name in ("xs", "rstd1", "rstd2", "qkv", "o", "lse_a", "lse_t", "h", "ab", "xn", "ssq_x", "ssq_h", "z", "xnf",
-                     "rstdN",
+        for name in ("xs", "rstd1", "rstd2", "qkv", "o", "lse_a", "lse_t", "h", "ab", "xn", "hn", "z", "xnf", "rstdN",
                      "dz", "dab", "dh", "dqkv", "attn_ws"):
             setattr(plan, name, getattr(ar, name).data_ptr())
         plan.dcur, plan.dnxt, plan.d_o = ar.da.data_ptr(), ar.db.data_ptr(), ar.do.data_ptr()
@@ -304,13 +296,12 @@ class StepEngine:
         R = ar.R
         adapter = m.adapter_query.weight.data.view(-1, A, D)     # (adapter_layer, A, D); model.py:304
         ops.cast_rows(adapter.reshape(L * A, D), ar.adapter_c.view(L * A, D))
-        ops.rmsnorm_fwd(ar.xs[0], pk.an[0], ar.xn, ar.rstd1[0], self.eps, rows=R)    # layer 0: rstd only
+        ops.rmsnorm_fwd(ar.xs[0], pk.an[0], ar.xn, ar.rstd1[0], self.eps, rows=R)
         for i in range(L):
             x = ar.xs[i]
-            # RMSNorm folded into the projection; rider: the adapter rows' K/V projections (model.py:98-100)
-            norm = dict(rstd_in=ar.rstd1[0]) if i == 0 else dict(ssq_in=ar.ssq_x, rstd_out=ar.rstd1[i])
-            ops.gemm_nt_ex(x, pk.wqkv_s[i], ar.qkv[i][:R], eps=self.eps, **norm,
-                           rider=(ar.adapter_c[i], pk.wqkv[i][D:], ar.qkv[i][R:, D:], False))
+            # sequence rows, and on the idle CUs the K/V projections of the adapter rows (model.py:98-100)
+            ops.gemm_nt_rider(ar.xn, pk.wqkv[i], ar.qkv[i][:R], rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:],
+                              rider_out=ar.qkv[i][R:, D:])
             g1, g2 = m.gate_views(i)
             if ops.attn_rope_fused(self.dtype):             # bf16 MFMA build: q,k stay raw, rotated inside
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F,
@@ -318,11 +309,14 @@ class StepEngine:
             else:
                 ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
-            ops.gemm_nt_ex(ar.o[i], pk.wo[i], ar.h[i], residual=x, ssq_out=ar.ssq_h)            # h = x + o·Wo^T
-            ops.gemm_nt_ex(ar.h[i], pk.w13_s[i], ar.ab[i], swiglu_z=ar.z, ssq_in=ar.ssq_h, rstd_out=ar.rstd2[i],
-                           eps=self.eps)                                                          # ab, z = silu(a)*b
-            ops.gemm_nt_ex(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i], ssq_out=ar.ssq_x)     # x' = h + z·W2^T
-        ops.rmsnorm_fwd(ar.xs[L], pk.norm, ar.xnf, ar.rstdN, self.eps, rows=R)
+            ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)           # h = x + o·Wo^T
+            ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
+            ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z)     # ab = hn·(W1|W3)^T, z = silu(a)*b
+            ops.gemm_nt(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i])   # x' = h + z·W2^T
+            if i + 1 < L:
+                ops.rmsnorm_fwd(ar.xs[i + 1], pk.an[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, rows=R)
+            else:
+                ops.rmsnorm_fwd(ar.xs[L], pk.norm, ar.xnf, ar.rstdN, self.eps, rows=R)
 
     # ------------------------------------------------------------------ backward
     def backward(self, g_losses: torch.Tensor, grads: "FlatParams"):

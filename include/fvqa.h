@@ -104,34 +104,6 @@ typedef struct fvqa_sk_rider {
 int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
                        int ldc, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider,
                        void* workspace, size_t workspace_bytes, void* stream);
-
-/* Options of fvqa_gemm_nt_ex — the persistent kernel with everything the layer schedule folds into a projection:
- *   rider     a second small product on the idle CUs (above), or NULL;
- *   z         FVQA_EPI_SWIGLU_FWD: the (M, N/2) SwiGLU output;
- *   ssq_in / n_ssq_in / rstd_in / eps / rstd_out — RMSNorm of A folded into the product (llama/model.py:37-42 in front
- *             of :89 and :142): B must hold W·diag(norm weight) (the host folds the frozen norm weight into the frozen
- *             projection once); every output row m is scaled by rstd[m] = rsqrt(sum_p ssq_in[m][p] / K + eps), with
- *             ssq_in (M, n_ssq_in) the partial row sums of squares the launch that wrote A left behind
- *             (n_ssq_in % 4 == 0), or — n_ssq_in == 0 — by rstd_in[m]; rstd_out (M) or NULL receives rstd (the
- *             backward of the norm needs it). (x·rstd)·W'^T == rstd·(x·W'^T): the normalised activations are never
- *             written. All NULL / 0: no norm.
- *   ssq_out   FVQA_EPI_NONE / RESIDUAL: per-row partial sums of squares of the output AS STORED, (M, 4*ceil(N/256))
- *             fp32 — [m][4*j + w] covers columns [256*j + 64*w, +64) — for the next projection's ssq_in; or NULL. */
-typedef struct fvqa_gemm_opts {
-  const fvqa_sk_rider* rider;
-  void* z;
-  const float* ssq_in;
-  const float* rstd_in;
-  float* rstd_out;
-  float* ssq_out;
-  int32_t n_ssq_in;
-  float eps;
-} fvqa_gemm_opts;
-/* C = epilogue(A·B^T) on the persistent kernel only (needs its workspace; N % 8 == 0); opts may be NULL. */
-int fvqa_gemm_nt_ex(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb, int ldc,
-                    int dtype, int out_dtype, int epilogue, const fvqa_gemm_opts* opts, void* workspace,
-                    size_t workspace_bytes, void* stream);
-
 int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
                           int32_t* segs_out, int max_segs);
 /* Measurement probe (bench.py roofline; no reference counterpart): while enabled, every launch of the
@@ -280,8 +252,6 @@ typedef struct fvqa_layer_plan {
   const void* const* wo;     /* (D, D)   */
   const void* const* w13;    /* (2Hf, D): W1 | W3 rows interleaved in blocks of 16 (AB16) */
   const void* const* w2;     /* (D, Hf)  */
-  const void* const* wqkv_s; /* (3D, D): wqkv with the attention-norm weight folded into its columns (W·diag(w)) */
-  const void* const* w13_s;  /* (2Hf, D): w13 (AB16) with the ffn-norm weight folded into its columns */
   const void* const* wqkv_t; /* (D, 3D)  */
   const void* const* wo_t;   /* (D, D)   */
   const void* const* w13_t;  /* (D, 2Hf): transpose of w13 (AB16 columns) */
@@ -306,9 +276,8 @@ typedef struct fvqa_layer_plan {
   float* lse_t;
   void* h;                   /* (L, R, D)   */
   void* ab;                  /* (L, R, 2Hf), AB16 */
-  void* xn;                  /* (R, D) scratch (layer 0's normalised input, written and not read) */
-  float* ssq_x;              /* (R, 4*ceil(D/256)) partial row sums of squares of the residual stream x */
-  float* ssq_h;              /* (R, 4*ceil(D/256)) ... of h = x + attention output */
+  void* xn;                  /* (Ra, D) scratch */
+  void* hn;                  /* (R, D)  scratch */
   void* z;                   /* (R, Hf) scratch */
   void* xnf;                 /* (R, D) final-norm output */
   float* rstdN;              /* (R) */

@@ -276,7 +276,7 @@ __device__ __forceinline__ void store_swiglu(f32x4 (&acc)[8][4], char* smem, con
 
 template <int NP>
 __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs& a, int wid, int c, int team0, int jm,
-                                                int w, int lane, int tid) {
+                                                int w, int lane, int tid, int pstride) {
   constexpr int OWN = 8 / NP;
   const unsigned lane_off = (unsigned)(w * 32 * 1024 + lane * 16);   // this lane's 16 bytes of block 0 in a slab
   {
@@ -296,7 +296,7 @@ __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs
   if (tid == 0) {
     __hip_atomic_store(a.sync + 1 + wid, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int p = 0; p < NP; ++p)
-      if (p != c) (void)wait_epoch(a.sync + 1 + (team0 + p) * ts + jm, a.epoch, a.sync);
+      if (p != c) (void)wait_epoch(a.sync + 1 + (team0 + p * pstride) * ts + jm, a.epoch, a.sync);
 #ifdef FVQA_SK_ACQUIRE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // not needed while EVERY load of a partner's slab is an sc1 load
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -310,7 +310,7 @@ __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs
 #pragma unroll
   for (int q = 0; q < NP - 1; ++q) {
     const int p = q < c ? q : q + 1;                      // partner piece
-    const float* sl = a.slabs + (size_t)((team0 + p) * ts + jm) * SLAB_FLOATS;
+    const float* sl = a.slabs + (size_t)((team0 + p * pstride) * ts + jm) * SLAB_FLOATS;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sl), 0, SLAB_FLOATS * 4, 0x00020000);
     // my tile row block c*OWN + i sits in partner p's register block ((c ^ p) * OWN + i)
     const unsigned boff = lane_off + (unsigned)(((c ^ p) * OWN) * 4 * 1024);
@@ -381,10 +381,10 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
     const int tid_e = w_e * 64 + lane_e;
     if (s.n == 1) __syncthreads();                        // every wave is done reading the ring
     else {
-      const int team0 = g - s.c;                          // team holding piece 0 of this tile
-      if (s.n == 2) exchange_reduce<2>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
-      else if (s.n == 4) exchange_reduce<4>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
-      else exchange_reduce<8>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e);
+      const int team0 = g - s.c * P.pstride;              // team holding piece 0 of this tile
+      if (s.n == 2) exchange_reduce<2>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
+      else if (s.n == 4) exchange_reduce<4>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
+      else exchange_reduce<8>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
     }
     SK_STAMP(4);
     if constexpr (EPI == FVQA_EPI_SWIGLU_FWD) {
@@ -442,8 +442,8 @@ extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, i
   if (K % wide) return FVQA_ESHAPE;
   const fvqa_sk_plan p = fvqa_sk_make_plan(M, N, K, wide, n_cu);
   if (plan_out) {
-    const int32_t v[11] = {p.tm, p.tn, p.nw_tile, p.gran, p.gpt, p.ts, p.mgroups, p.n_teams, p.full, p.rem, p.s};
-    for (int i = 0; i < 11; ++i) plan_out[i] = v[i];
+    const int32_t v[12] = {p.tm, p.tn, p.nw_tile, p.gran, p.gpt, p.ts, p.mgroups, p.n_teams, p.full, p.rem, p.s, p.pstride};
+    for (int i = 0; i < 12; ++i) plan_out[i] = v[i];
   }
   int n = 0;
   if (team >= 0 && team < p.n_teams) {

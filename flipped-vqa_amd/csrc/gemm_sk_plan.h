@@ -22,7 +22,8 @@
 //     s pieces (s = 1, 2, 4 or 8, the largest with s * rem <= teams and >= 2 granules per piece), one per team.
 //     The s workgroups of a tile have done the same work before, finish together and share the reduction: each adds
 //     128/s rows of every wave's 128 x 64 sub-tile from all s partials (fixed order 0..s-1: bitwise repeatable) and
-//     stores them with the epilogue. N = 4096 outputs (64 tiles for 256 CUs) are the case full = 0, s = 4.
+//     stores them with the epilogue. N = 4096 outputs (64 tiles for 256 CUs) are the case full = 0, s = 4; there the
+//     piece index is constant per XCD (pstride), which keeps each XCD's L2 on one K range of the activations.
 #pragma once
 #include <stdint.h>
 
@@ -43,12 +44,13 @@ struct fvqa_sk_plan {
   int32_t full;          // rounds of whole tiles
   int32_t rem;           // tiles of the last, split round
   int32_t s;             // pieces per tile of the last round
+  int32_t pstride;       // team distance between consecutive pieces of a tile (piece p of a tile: team0 + p * pstride)
 };
 
 struct fvqa_sk_seg {
   int32_t tile;          // tile index in walk order: n tile = tile / mgroups, m group = tile % mgroups
   int32_t k0, k1;        // wide stages [k0, k1) of the tile's K range
-  int32_t n, c;          // piece c of n; piece p of the tile is held by team (tile - full * teams) * n + p
+  int32_t n, c;          // piece c of n; piece p of the tile is held by team g + (p - c) * pstride
 };
 
 FVQA_HD int fvqa_sk_tiles(const fvqa_sk_plan& p) { return p.mgroups * p.tn; }
@@ -60,7 +62,13 @@ FVQA_HD bool fvqa_sk_segment(const fvqa_sk_plan& p, int g, int idx, fvqa_sk_seg*
     return true;
   }
   if (idx > p.full || g >= p.rem * p.s) return false;
-  const int r = g / p.s, c = g - r * p.s;
+  int r, c;
+  if (p.pstride == 1) {                                           // the pieces of a tile on consecutive teams
+    r = g / p.s; c = g - r * p.s;
+  } else {                                                          // piece index constant per XCD (see make_plan)
+    const int x = g / p.pstride, y = g - x * p.pstride;
+    c = x % p.s; r = (x / p.s) * p.pstride + y;
+  }
   const int qq = p.gpt / p.s, rr = p.gpt - qq * p.s;               // granules per piece, first rr pieces one more
   const int g0 = c * qq + (c < rr ? c : rr), g1 = g0 + qq + (c < rr ? 1 : 0);
   s->tile = p.full * p.n_teams + r;
@@ -90,5 +98,13 @@ static inline fvqa_sk_plan fvqa_sk_make_plan(int M, int N, int K, int wide_elems
   p.s = 1;
   while (p.rem > 0 && p.s < 8 && p.rem * p.s * 2 <= teams && p.gpt / (p.s * 2) >= 2) p.s *= 2;
   p.n_teams = p.full > 0 ? teams : p.rem * p.s;
+  // A pure split launch that fills 8 equal XCD chunks of teams (the kernel gives consecutive work ids to one XCD): every
+  // team of an XCD takes the SAME piece index, so an XCD's L2 sees one K range of the activations instead of all of K
+  // (measured on W1|W3^T: 4x fewer activation bytes leave L2). The partners of a tile then sit pstride teams apart, on
+  // different XCDs — their exchange goes through write-through slabs wherever they sit.
+  p.pstride = 1;
+  if (p.full == 0 && p.s > 1 && p.n_teams % 8 == 0 && (p.n_teams * p.ts) % 8 == 0 && 8 % p.s == 0 &&
+      p.rem * p.s == p.n_teams)
+    p.pstride = p.n_teams / 8;
   return p;
 }

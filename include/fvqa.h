@@ -83,8 +83,9 @@ size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
  * once with the epilogue.
  * fvqa_gemm_sk_workspace: 4096 flag bytes + one 256 KiB fp32 partial-tile slab per workgroup.
  * fvqa_gemm_sk_describe (host only, no GPU touched): the partition for a problem on n_cu compute units —
- * plan_out[11] = {tm, tn, wide stages per tile, stages per granule, granules per tile, team size, m groups, teams,
- * rounds of whole tiles, tiles of the last (split) round, pieces per tile there}; for team >= 0 also its segments, 5 ints each
+ * plan_out[12] = {tm, tn, wide stages per tile, stages per granule, granules per tile, team size, m groups, teams,
+ * rounds of whole tiles, tiles of the last (split) round, pieces per tile there, team distance between the pieces of a
+ * tile}; for team >= 0 also its segments, 5 ints each
  * {tile, k0, k1, pieces n, piece c} (up to max_segs written); returns the team's segment count. */
 size_t fvqa_gemm_sk_workspace(void);
 

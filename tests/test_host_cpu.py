@@ -225,9 +225,9 @@ def test_bench_launcher_command_and_env():
 def _sk_plan(M, N, K, dtype, n_cu=256):
     import ctypes as C
     lib = _lib.load()
-    plan = (C.c_int32 * 11)()
+    plan = (C.c_int32 * 12)()
     lib.fvqa_gemm_sk_describe(M, N, K, dtype, n_cu, C.cast(plan, C.c_void_p), -1, None, 0)
-    keys = ("tm", "tn", "nw_tile", "gran", "gpt", "ts", "mgroups", "n_teams", "full", "rem", "s")
+    keys = ("tm", "tn", "nw_tile", "gran", "gpt", "ts", "mgroups", "n_teams", "full", "rem", "s", "pstride")
     p = dict(zip(keys, list(plan)))
     segs = []
     for g in range(p["n_teams"]):
@@ -249,9 +249,9 @@ def _sk_plan(M, N, K, dtype, n_cu=256):
     (2048, 2048, 2048, 1), (1024, 4096, 4096, 0), (4096, 4096, 4096, 1), (8192, 8192, 8192, 1), (256, 4096, 4096, 1)])
 def test_persistent_gemm_partition_covers_every_tile_once(M, N, K, dtype):
     """The (tile, K range) partition of csrc/gemm_sk_plan.h, walked through the host-only C entry: every wide stage of
-    every tile is computed exactly once; a split tile has 2, 4 or 8 pieces in K order held by consecutive teams as
+    every tile is computed exactly once; a split tile has 2, 4 or 8 pieces in K order held by teams `pstride` apart as
     their LAST segment after the same number of whole tiles (partners finish together; nobody waits on a workgroup
-    that still has other work to do first)."""
+    that still has other work to do first); with pstride > 1 all teams of an XCD chunk hold the same piece index."""
     for n_cu in (256, 304, 64):
         p, segs = _sk_plan(M, N, K, dtype, n_cu)
         assert p["n_teams"] * p["ts"] <= n_cu and p["ts"] * p["mgroups"] >= p["tm"]
@@ -274,8 +274,10 @@ def test_persistent_gemm_partition_covers_every_tile_once(M, N, K, dtype):
             for c, s in enumerate(ss):
                 assert s["n"] == n and s["c"] == c
                 if n > 1:
-                    assert s["team"] == ss[0]["team"] + c and s["order"] == p["full"] == n_seg[s["team"]] - 1
+                    assert s["team"] == ss[0]["team"] + c * p["pstride"] and s["order"] == p["full"] == n_seg[s["team"]] - 1
                     assert s["k1"] - s["k0"] > p["gran"]
+                    if p["pstride"] > 1:
+                        assert s["c"] == (s["team"] // p["pstride"]) % n
 
 
 def test_persistent_gemm_plans_of_the_c2_step():
@@ -287,3 +289,4 @@ def test_persistent_gemm_plans_of_the_c2_step():
     for (N, K), w in want.items():
         p, _ = _sk_plan(1024, N, K, 1)
         assert (p["n_teams"], p["full"], p["rem"], p["s"]) == w and p["ts"] == 4, (N, K, p)
+        assert p["pstride"] == (8 if w[3] == 4 else 1)

@@ -42,55 +42,106 @@ __global__ __launch_bounds__(256) void visual_proj_fwd_k(const float* __restrict
   }
 }
 
-// vf_tok[r,d] = storage-dtype cast of vf_raw[r,d] + temporal[r % F, d]   (after the GEMM form of the projection)
-template <typename T>
-__global__ __launch_bounds__(256) void visual_tok_k(const float* __restrict__ vf_raw,
-                                                    const float* __restrict__ temporal, T* __restrict__ vf_tok,
-                                                    int R, int F, int D) {
-  const size_t n4 = (size_t)R * D / 4;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const int r = (int)(i * 4 / D), d = (int)(i * 4 % D);
-    float v[4], t[4];
-    Vec4<float>::load(vf_raw + i * 4, v);
-    Vec4<float>::load(temporal + (size_t)(r % F) * D + d, t);
-    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-    Vec4<T>::store(vf_tok + i * 4, v);
-  }
-}
-
-// dW[d,k] += sum_r (d_tok[r,d] + d_qav[r,d]) * video[r,k]
-template <int KMAX>
+// dW[d,k] += sum_r (d_tok[r,d] + d_qav[r,d]) * video[r,k]   (the weight gradient of llama/model.py:322).
+// One wave owns DB output features and the whole K row of each in registers (DB x K/64 accumulators), so a frame row of
+// `video` fetched from L2 feeds DB features: 8x fewer bytes through L2 than one feature per wave (105 -> ~15 us at 7B).
+template <int KMAX, int DB>
 __global__ __launch_bounds__(256) void visual_proj_bwd_k(const float* __restrict__ d_tok,
                                                          const float* __restrict__ d_qav,
                                                          const float* __restrict__ video, float* __restrict__ dW,
                                                          int R, int K, int D) {
-  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (d >= D) return;
+  const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DB;
+  if (d0 >= D) return;
   const int lane = threadIdx.x & 63;
-  float acc[KMAX];
+  float acc[DB][KMAX];
 #pragma unroll
-  for (int t = 0; t < KMAX; ++t) acc[t] = 0.f;
+  for (int j = 0; j < DB; ++j)
+#pragma unroll
+    for (int t = 0; t < KMAX; ++t) acc[j][t] = 0.f;
   for (int r = 0; r < R; ++r) {
-    float g = d_tok[(size_t)r * D + d];
-    if (d_qav) g += d_qav[(size_t)r * D + d];
+    float g[DB];
+#pragma unroll
+    for (int j = 0; j < DB; ++j) {
+      const int d = d0 + j < D ? d0 + j : D - 1;
+      g[j] = d_tok[(size_t)r * D + d];
+      if (d_qav) g[j] += d_qav[(size_t)r * D + d];
+    }
 #pragma unroll
     for (int t = 0; t < KMAX / 4; ++t) {
       const int k = t * 256 + lane * 4;
       if (k < K) {
         float v[4];
         Vec4<float>::load(video + (size_t)r * K + k, v);
-        acc[4 * t] += g * v[0]; acc[4 * t + 1] += g * v[1]; acc[4 * t + 2] += g * v[2]; acc[4 * t + 3] += g * v[3];
+#pragma unroll
+        for (int j = 0; j < DB; ++j) {
+          acc[j][4 * t] += g[j] * v[0]; acc[j][4 * t + 1] += g[j] * v[1];
+          acc[j][4 * t + 2] += g[j] * v[2]; acc[j][4 * t + 3] += g[j] * v[3];
+        }
       }
     }
   }
 #pragma unroll
-  for (int t = 0; t < KMAX / 4; ++t) {
-    const int k = t * 256 + lane * 4;
-    if (k < K) {
-      float v[4];
-      Vec4<float>::load(dW + (size_t)d * K + k, v);
-      v[0] += acc[4 * t]; v[1] += acc[4 * t + 1]; v[2] += acc[4 * t + 2]; v[3] += acc[4 * t + 3];
-      Vec4<float>::store(dW + (size_t)d * K + k, v);
+  for (int j = 0; j < DB; ++j) {
+    if (d0 + j >= D) break;
+#pragma unroll
+    for (int t = 0; t < KMAX / 4; ++t) {
+      const int k = t * 256 + lane * 4;
+      if (k < K) {
+        float v[4];
+        Vec4<float>::load(dW + (size_t)(d0 + j) * K + k, v);
+        v[0] += acc[j][4 * t]; v[1] += acc[j][4 * t + 1]; v[2] += acc[j][4 * t + 2]; v[3] += acc[j][4 * t + 3];
+        Vec4<float>::store(dW + (size_t)(d0 + j) * K + k, v);
+      }
+    }
+  }
+}
+
+// vf_raw[r,d] = video[r,:]·W[d,:] on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: the same fma chain per
+// output as a scalar loop over k in 16-element strides), then vf_tok = cast(vf_raw + temporal[r % F]). One workgroup
+// per 16 output features: its 4 waves split K, each keeps the R <= 128 frame rows as 16-row MFMA blocks; the 4
+// partial sums meet in LDS. 256 workgroups instead of the 32 tiles of a 128x128 GEMM at M = 80: 69 -> ~8 us.
+template <typename T>
+__global__ __launch_bounds__(256) void visual_proj_fwd_mfma_k(const float* __restrict__ video,
+                                                              const float* __restrict__ W,
+                                                              const float* __restrict__ temporal,
+                                                              float* __restrict__ vf_raw, T* __restrict__ vf_tok,
+                                                              int R, int F, int K, int D) {
+  __shared__ float part[4][8][16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int nrb = (R + 15) >> 4;                           // 16-row blocks of frame rows (<= 8)
+  const int kw = K / 4;                                    // this wave's K range (K % 64 == 0)
+  int bn = n0 + li; bn = bn < D ? bn : D - 1;
+  const float* bp = W + (size_t)bn * K + (size_t)w * kw + 4 * g;
+  f32x4 acc[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < kw; k0 += 16) {
+    const float4 bf = *reinterpret_cast<const float4*>(bp + k0);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      if (b >= nrb) break;
+      int ar = b * 16 + li; ar = ar < R ? ar : R - 1;
+      const float4 af = *reinterpret_cast<const float4*>(video + (size_t)ar * K + (size_t)w * kw + k0 + 4 * g);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc[b], 0, 0, 0);     // D[row 4g+e][feature li]
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc[b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[w][b][4 * g + e][li] = acc[b][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < nrb * 256; i += 256) {
+    const int b = i >> 8, rr = (i >> 4) & 15, c = i & 15;
+    const int r = b * 16 + rr, d = n0 + c;
+    if (r < R && d < D) {
+      const float v = ((part[0][b][rr][c] + part[1][b][rr][c]) + part[2][b][rr][c]) + part[3][b][rr][c];
+      vf_raw[(size_t)r * D + d] = v;
+      vf_tok[(size_t)r * D + d] = from_f32<T>(v + temporal[(size_t)(r % F) * D + d]);
     }
   }
 }
@@ -316,20 +367,16 @@ extern "C" int fvqa_visual_proj_fwd(const float* video, const float* W, const fl
   dim3 grid((dim + 3) / 4), block(256);
   hipStream_t st = (hipStream_t)stream;
   // The wave-per-feature kernel re-reads the whole frame matrix for every output feature (1 GB of L2 traffic at
-  // D = 4096: 120 us). When the shapes fit the exact-fp32 MFMA GEMM (K % 32 == 0, 16-byte rows) the product runs
-  // there (same fp32 fma chains, ~10 us) and a small pass adds the temporal embedding and casts.
-  if (in_dim % 32 == 0 && dim % 4 == 0 && !(((uintptr_t)video | (uintptr_t)W | (uintptr_t)vf_raw) & 15)) {
-    int rc = fvqa_gemm_nt(video, W, vf_raw, nullptr, nullptr, n_frames_total, dim, in_dim, in_dim, in_dim, dim,
-                          n_frames_total, FVQA_F32, FVQA_F32, FVQA_EPI_NONE, 2, nullptr, 0, stream);
-    if (rc) return rc;
-    const size_t n4 = (size_t)n_frames_total * dim / 4;
-    const int g = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
+  // D = 4096: 120 us). Shapes of the step (K % 64 == 0, at most 128 frame rows, 16-byte rows) run on the exact-fp32
+  // matrix cores instead, temporal embedding and cast included.
+  if (in_dim % 64 == 0 && n_frames_total <= 128 && !(((uintptr_t)video | (uintptr_t)W) & 15)) {
+    const dim3 g16((dim + 15) / 16);
     if (dtype == FVQA_BF16)
-      hipLaunchKernelGGL(visual_tok_k<bf16_t>, dim3(g), block, 0, st, vf_raw, temporal, (bf16_t*)vf_tok,
-                         n_frames_total, max_feats, dim);
+      hipLaunchKernelGGL(visual_proj_fwd_mfma_k<bf16_t>, g16, block, 0, st, video, W, temporal, vf_raw, (bf16_t*)vf_tok,
+                         n_frames_total, max_feats, in_dim, dim);
     else
-      hipLaunchKernelGGL(visual_tok_k<float>, dim3(g), block, 0, st, vf_raw, temporal, (float*)vf_tok, n_frames_total,
-                         max_feats, dim);
+      hipLaunchKernelGGL(visual_proj_fwd_mfma_k<float>, g16, block, 0, st, video, W, temporal, vf_raw, (float*)vf_tok,
+                         n_frames_total, max_feats, in_dim, dim);
     FVQA_CHECK_LAUNCH();
     return FVQA_OK;
   }
@@ -351,8 +398,12 @@ extern "C" int fvqa_visual_proj_bwd(const float* d_tok, const float* d_qav, cons
       in_dim > 2048 || dim <= 0)
     return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((visual_proj_bwd_k<32>), dim3((dim + 3) / 4), dim3(256), 0, st, d_tok, d_qav, video, dW,
-                     n_frames_total, in_dim, dim);
+  if (in_dim <= 1024)        // 8 features per wave (8 x 16 accumulators)
+    hipLaunchKernelGGL((visual_proj_bwd_k<16, 8>), dim3((dim + 31) / 32), dim3(256), 0, st, d_tok, d_qav, video, dW,
+                       n_frames_total, in_dim, dim);
+  else
+    hipLaunchKernelGGL((visual_proj_bwd_k<32, 4>), dim3((dim + 15) / 16), dim3(256), 0, st, d_tok, d_qav, video, dW,
+                       n_frames_total, in_dim, dim);
   hipLaunchKernelGGL(temporal_bwd_k, dim3((max_feats * dim + 255) / 256), dim3(256), 0, st, d_tok, dtemporal,
                      n_frames_total / max_feats, max_feats, dim);
   FVQA_CHECK_LAUNCH();

@@ -6,9 +6,11 @@
 
 namespace {
 
-constexpr int NB = 64;   // partial blocks per segment
+constexpr int NB = 256;  // partial blocks per segment (the largest segment, visual_proj.weight, is 3.1 M scalars)
 
-// grid (NB, n_seg): g *= 1/scale in place; partial sum of squares + non-finite flag per block
+// grid (NB, n_seg): g *= 1/scale in place; partial sum of squares + non-finite flag per block. 16-byte accesses on the
+// aligned body of a segment, scalars on its ragged ends; a block's elements and their order are fixed, so the norm is
+// bitwise repeatable.
 __global__ __launch_bounds__(256) void unscale_sq_k(float* __restrict__ grad, const int64_t* __restrict__ seg_off,
                                                     const float* __restrict__ scale, float* __restrict__ part) {
   __shared__ float red[4];
@@ -16,11 +18,26 @@ __global__ __launch_bounds__(256) void unscale_sq_k(float* __restrict__ grad, co
   const int64_t lo = seg_off[seg], hi = seg_off[seg + 1];
   const float inv = 1.f / scale[0];
   float sq = 0.f, bad = 0.f;
-  for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)NB * 256) {
+  auto one = [&](int64_t i) {
     const float g = grad[i] * inv;
     grad[i] = g;
     sq += g * g;
     if (!isfinite(g)) bad = 1.f;
+  };
+  const int64_t a0 = (lo + 3) & ~(int64_t)3, a1 = hi & ~(int64_t)3;       // 16-byte aligned body [a0, a1)
+  if (a0 < a1) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < a0 - lo) one(lo + t);                                         // (< 4 elements)
+    if (t < hi - a1) one(a1 + t);
+    for (int64_t i = a0 + 4 * t; i < a1; i += (int64_t)NB * 256 * 4) {
+      float4 g = *reinterpret_cast<float4*>(grad + i);
+      g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+      *reinterpret_cast<float4*>(grad + i) = g;
+      sq += g.x * g.x; sq += g.y * g.y; sq += g.z * g.z; sq += g.w * g.w;
+      if (!isfinite(g.x) || !isfinite(g.y) || !isfinite(g.z) || !isfinite(g.w)) bad = 1.f;
+    }
+  } else {
+    for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)NB * 256) one(i);
   }
   sq = block_sum_256(sq, red);
   bad = block_sum_256(bad, red);

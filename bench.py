@@ -51,9 +51,9 @@ def step_flops(D, H, L, Hf, V, N, S, A, F, tasks):
     return tot
 
 
-def cpu_baseline_leg(seq_len, max_feats):
-    """Oracle fwd+bwd at 7B width on the host cores, bounded: 1 and 2 layers, B=2, VQA only;
-    the per-layer and the fixed cost are separated and scaled to 32 layers."""
+def _cpu_extrapolated(seq_len, max_feats):
+    """Fallback: oracle fwd+bwd at 7B width for 1 and 2 layers, B=2, VQA only; per-layer and fixed cost separated and
+    scaled to 32 layers."""
     from fvqa import synth
     from oracle import ref_cpu
     times = {}
@@ -70,15 +70,44 @@ def cpu_baseline_leg(seq_len, max_feats):
             best = min(best, time.perf_counter() - t0)
         times[L] = best
         del model
-    # two-point fit: fixed cost (embedding, LM head, CE) + per-layer cost; guarded against noise
     per_layer = times[2] - times[1]
     if not (0.15 * times[2] < per_layer < times[1]):
         per_layer = times[2] / 3.0
     fixed = max(times[1] - per_layer, 0.0)
     full = fixed + 32 * per_layer              # one 7B step on B=2 samples
     return {"value": 2.0 / full, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "method": "extrapolated",
             "sample": f"oracle/ref_cpu.py fp32, 7B width, B=2 S={seq_len} VQA-only, timed at 1 and 2 layers "
                       f"({times[1]:.2f}s, {times[2]:.2f}s) and scaled to 32 layers + head ({full:.1f}s/step)"}
+
+
+def cpu_baseline_leg(seq_len, max_feats):
+    """The CPU oracle (oracle/ref_cpu.py, fp32) timed on this host's cores on a bounded sample of the workload: ONE full
+    step (forward + backward, all 32 layers of the 7B, VQA loss) on B=2 samples of the same sequence length — the
+    reference's own batch for its CPU-runnable configuration. The 27 GB of closed-form fp32 weights are generated on the
+    GPU tensor by tensor and copied to the host (the generator is the same counter hash on either device). Falls back
+    to the 1- and 2-layer extrapolation if the full-depth model cannot be built (host memory)."""
+    from fvqa import synth
+    from oracle import ref_cpu
+    try:
+        cfg = synth.preset("7b", max_seq_len=seq_len, max_feats=max_feats, batch_size=2)
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        sd = {n: synth.make_tensor(cfg, n, shape, kind, device=dev).cpu() for n, shape, kind in synth.state_spec(cfg)}
+        model = ref_cpu.RefModel(cfg, sd, dtype=torch.float32)
+        del sd
+        batch = synth.make_batch(cfg, seed=0)
+        t0 = time.perf_counter()
+        model.step(batch)
+        dt = time.perf_counter() - t0
+        del model
+        return {"value": 2.0 / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "method": "measured_full_depth",
+                "sample": f"oracle/ref_cpu.py fp32, full LLaMA-7B (32 layers), ONE forward+backward step on B=2 "
+                          f"samples, S={seq_len}, VQA loss: {dt:.1f}s"}
+    except (RuntimeError, MemoryError) as e:
+        out = _cpu_extrapolated(seq_len, max_feats)
+        out["fallback_reason"] = repr(e)[:200]
+        return out
 
 
 def launcher_command(n_gpus, argv, port=None, python=None):
@@ -256,13 +285,19 @@ def main():
             tot_f = sum(v[1] for v in per.values())
             n = sum(v[2] for v in per.values())
             peak = MFMA_BF16_PEAK if a.dtype == "bf16" else 157.3e12
+            # HBM-side bytes per launch from the rocprofv3 --pmc passes of THIS command (tools/pmc_summary.py: FETCH_SIZE x2
+            # gfx950 correction + WRITE_SIZE), valid only for the library version they were collected at; else null
             traffic, tsrc = None, None
-            tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
-            if a.dtype == "bf16" and a.model == "7B" and not (a.vaq or a.qav) and os.path.exists(tj):
-                pm = json.load(open(tj))                 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-                w_ = [(v["launches_sampled"], v["hbm_bytes_per_launch"]) for k, v in pm.items() if "float," not in k]
-                traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
-                tsrc = "profiles/r01_pmc_gemm_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, same workload)"
+            tj = os.path.join(ROOT, "profiles", "r02_pmc_mfma_lds.json")
+            if a.dtype == "bf16" and a.model == "7B" and not (a.vaq or a.qav) and a.seq_len == 128 and os.path.exists(tj):
+                pm = json.load(open(tj))
+                from fvqa import _lib
+                if pm.get("fvqa_version") == int(_lib.load().fvqa_version()):
+                    w_ = [(v["launches_sampled"], v["hbm_bytes_per_launch"]) for k, v in pm.get("kernels", {}).items()
+                          if k.startswith("gemm_sk_256") and "hbm_bytes_per_launch" in v]
+                    if w_:
+                        traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
+                        tsrc = f"profiles/r02_pmc_mfma_lds.json (measured at fvqa_version {pm['fvqa_version']}, same workload)"
             roof = {"bound": "mfma",
                     "kernel": "gemm_sk_256 (every launch of every instantiation in the step: persistent 256x256-tile LDS-DMA ring kernel, split-K reduced in the launch)",
                     "achieved": tot_f / tot_t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void visual_proj_fwd_k(const float* __restrict
 
 // dW[d,k] += sum_r (d_tok[r,d] + d_qav[r,d]) * video[r,k]   (the weight gradient of llama/model.py:322).
 // One wave owns DB output features and the whole K row of each in registers (DB x K/64 accumulators), so a frame row of
-// `video` fetched from L2 feeds DB features: 8x fewer bytes through L2 than one feature per wave (105 -> ~15 us at 7B).
+// `video` fetched from L2 feeds DB features (DB x fewer bytes through L2 than one feature per wave), four rows per trip.
 template <int KMAX, int DB>
 __global__ __launch_bounds__(256) void visual_proj_bwd_k(const float* __restrict__ d_tok,
                                                          const float* __restrict__ d_qav,
@@ -58,27 +58,34 @@ __global__ __launch_bounds__(256) void visual_proj_bwd_k(const float* __restrict
   for (int j = 0; j < DB; ++j)
 #pragma unroll
     for (int t = 0; t < KMAX; ++t) acc[j][t] = 0.f;
-  for (int r = 0; r < R; ++r) {
-    float g[DB];
+  for (int r0 = 0; r0 < R; r0 += 4) {                      // 4 frame rows per trip: their loads are all in flight together
+    float g[4][DB];
+    float v[4][KMAX];
 #pragma unroll
-    for (int j = 0; j < DB; ++j) {
-      const int d = d0 + j < D ? d0 + j : D - 1;
-      g[j] = d_tok[(size_t)r * D + d];
-      if (d_qav) g[j] += d_qav[(size_t)r * D + d];
-    }
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = r0 + rr < R ? r0 + rr : R - 1;
+      const float live = r0 + rr < R ? 1.f : 0.f;
 #pragma unroll
-    for (int t = 0; t < KMAX / 4; ++t) {
-      const int k = t * 256 + lane * 4;
-      if (k < K) {
-        float v[4];
-        Vec4<float>::load(video + (size_t)r * K + k, v);
+      for (int j = 0; j < DB; ++j) {
+        const int d = d0 + j < D ? d0 + j : D - 1;
+        float gv = d_tok[(size_t)r * D + d];
+        if (d_qav) gv += d_qav[(size_t)r * D + d];
+        g[rr][j] = gv * live;
+      }
 #pragma unroll
-        for (int j = 0; j < DB; ++j) {
-          acc[j][4 * t] += g[j] * v[0]; acc[j][4 * t + 1] += g[j] * v[1];
-          acc[j][4 * t + 2] += g[j] * v[2]; acc[j][4 * t + 3] += g[j] * v[3];
-        }
+      for (int t = 0; t < KMAX / 4; ++t) {
+        const int k = t * 256 + lane * 4;
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k < K) Vec4<float>::load(video + (size_t)r * K + k, q);
+        v[rr][4 * t] = q[0]; v[rr][4 * t + 1] = q[1]; v[rr][4 * t + 2] = q[2]; v[rr][4 * t + 3] = q[3];
       }
     }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)                         // rows in order: the same fma chain as a row-by-row loop
+#pragma unroll
+      for (int j = 0; j < DB; ++j)
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) acc[j][t] += g[rr][j] * v[rr][t];
   }
 #pragma unroll
   for (int j = 0; j < DB; ++j) {
@@ -398,11 +405,11 @@ extern "C" int fvqa_visual_proj_bwd(const float* d_tok, const float* d_qav, cons
       in_dim > 2048 || dim <= 0)
     return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
-  if (in_dim <= 1024)        // 8 features per wave (8 x 16 accumulators)
-    hipLaunchKernelGGL((visual_proj_bwd_k<16, 8>), dim3((dim + 31) / 32), dim3(256), 0, st, d_tok, d_qav, video, dW,
+  if (in_dim <= 1024)        // 4 features per wave (4 x 16 accumulators), 4 waves per CU at D = 4096
+    hipLaunchKernelGGL((visual_proj_bwd_k<16, 4>), dim3((dim + 15) / 16), dim3(256), 0, st, d_tok, d_qav, video, dW,
                        n_frames_total, in_dim, dim);
   else
-    hipLaunchKernelGGL((visual_proj_bwd_k<32, 4>), dim3((dim + 15) / 16), dim3(256), 0, st, d_tok, d_qav, video, dW,
+    hipLaunchKernelGGL((visual_proj_bwd_k<32, 2>), dim3((dim + 7) / 8), dim3(256), 0, st, d_tok, d_qav, video, dW,
                        n_frames_total, in_dim, dim);
   hipLaunchKernelGGL(temporal_bwd_k, dim3((max_feats * dim + 255) / 256), dim3(256), 0, st, d_tok, dtemporal,
                      n_frames_total / max_feats, max_feats, dim);

@@ -69,8 +69,15 @@ def main():
                 if src in avg:
                     e[dst] = avg[src] / avg["SQ_WAVE_CYCLES"]
         res[k] = e
-    json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps(res, indent=1))
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "flipped-vqa_amd"))
+    from fvqa import _lib                                   # host-only call: the ABI version the passes ran against
+    doc = {"fvqa_version": int(_lib.load().fvqa_version()),
+           "command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 2 --warmup 1 "
+                      "--no_cpu_baseline (C2: LLaMA-7B bf16 B=8 S=128 VQA)",
+           "kernels": res}
+    json.dump(doc, open(out, "w"), indent=1)
+    print(json.dumps(doc, indent=1))
 
 
 if __name__ == "__main__":

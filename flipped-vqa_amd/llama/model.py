@@ -211,7 +211,10 @@ class Transformer(nn.Module):
         else:
             losses = eng.forward(data)
         vqa_loss = losses[0]
-        zero = lambda: torch.tensor([0], device=losses.device)      # noqa: E731  (llama/model.py:302)
+        # tensor([0]) of a switched-off loss (llama/model.py:302), made ON the device: torch.tensor([0], device=...) is a
+        # pageable host-to-device copy, which blocks the host until the stream reaches it — i.e. until the whole forward
+        # has run — and the backward then starts late (C2 step: 29.7 -> 28.7 ms, profiles/r02_gemm_partition_probe.log section 7)
+        zero = lambda: torch.zeros(1, dtype=torch.int64, device=losses.device)      # noqa: E731
         vaq_loss = losses[1] if self.args.vaq else zero()
         qav_loss = losses[2] if self.args.qav else zero()
         return vqa_loss, vaq_loss, qav_loss

@@ -3,8 +3,17 @@ engine.py:10-56): per-iteration LR schedule, forward, sum of the three flipped l
 check, gradient accumulation through the loss scaler, meters.
 
 Host-side differences that do not change results: the three loss values come back in ONE
-device->host transfer per iteration instead of four `.item()` calls + a full device sync, and the
-logging period is clamped to >= 1 (the reference crashes on loaders shorter than 4 batches).
+device->host transfer per iteration instead of four `.item()` calls + a full device sync; that
+transfer is WAITED FOR only after the backward (and, at an accumulation boundary, the optimizer
+step) of the iteration has been launched, so the device never idles while the host reads the
+loss (reading first, as the reference does, leaves the GPU idle from the end of the forward until
+the host has issued the first backward kernel: 0.5-1 ms of a 29 ms step). A non-finite loss still
+prints the reference's message and exits with status 1 before anything else happens on the host;
+the one difference is that the backward / optimizer step of THAT iteration has already been queued
+on the device when the process exits (a non-finite gradient is skipped by the fused optimizer; a
+finite one — e.g. the other two losses when only one CE had no scored token — is applied), which
+nothing observes: the reference's train.py does not catch the exit and saves nothing after it. The logging period is clamped to >= 1 (the reference crashes on loaders shorter
+than 4 batches).
 """
 import math
 import sys
@@ -24,6 +33,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     n_iter = len(data_loader)
     accum = args.accum_iter
     optimizer.zero_grad()
+    host_vals, copied = None, None
 
     for it, data in enumerate(log.log_every(data_loader, n_iter // 4, f"Epoch: [{epoch}]")):
         boundary_start = it % accum == 0
@@ -33,14 +43,25 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
 
         vqa_loss, vaq_loss, qav_loss = model(data)
         loss = vqa_loss + vaq_loss + qav_loss
-        vals = torch.stack([vqa_loss.reshape(()).float(), vaq_loss.reshape(()).float(),
-                            qav_loss.reshape(()).float()]).tolist()       # one D2H copy (it also syncs)
+        vals_dev = torch.stack([vqa_loss.reshape(()).float(), vaq_loss.reshape(()).float(),
+                                qav_loss.reshape(()).float()])
+        if vals_dev.is_cuda:                                  # one asynchronous D2H copy into pinned memory
+            if host_vals is None:
+                host_vals, copied = torch.empty(3, dtype=torch.float32, pin_memory=True), torch.cuda.Event()
+            host_vals.copy_(vals_dev, non_blocking=True)
+            copied.record()
+
+        loss_scaler(loss / accum, optimizer, parameters=model.parameters(), update_grad=boundary_end)
+
+        if vals_dev.is_cuda:
+            copied.synchronize()                              # the forward has finished; the backward is queued
+            vals = host_vals.tolist()
+        else:
+            vals = vals_dev.tolist()
         loss_value = vals[0] + vals[1] + vals[2]
         if not math.isfinite(loss_value):
             print("Loss is {}, stopping training".format(loss_value))
             sys.exit(1)
-
-        loss_scaler(loss / accum, optimizer, parameters=model.parameters(), update_grad=boundary_end)
         if boundary_end:
             optimizer.zero_grad()
 

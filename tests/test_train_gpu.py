@@ -82,6 +82,32 @@ def test_train_one_epoch_contract_and_learning():
     assert opt.step_dev.item() == 4.0                        # 8 micro-steps / accum_iter 2
 
 
+def test_train_one_epoch_stops_on_a_non_finite_loss(capsys):
+    """All labels ignored -> the CE mean is 0/0 = NaN -> the reference prints and exits with status 1
+    (engine.py:33-35). The loss is read after the backward has been launched; the exit is the same."""
+    cfg, model, args, opt = _setup(torch.bfloat16)
+    args.accum_iter, args.lr, args.warmup_epochs, args.epochs = 1, 0.02, 0, 1
+    loader = synth.SyntheticLoader(cfg, 4)
+    for b in loader.batches:
+        b["label"]["vqa"] = torch.zeros_like(b["label"]["vqa"])          # ignore_index everywhere
+    with pytest.raises(SystemExit) as e:
+        engine.train_one_epoch(model, loader, opt, 0, misc.NativeScalerWithGradNormCount(), args=args)
+    assert e.value.code == 1
+    assert "Loss is nan, stopping training" in capsys.readouterr().out
+    torch.cuda.synchronize()
+    assert opt.step_dev.item() <= 1.0                        # it stopped at the FIRST iteration
+
+
+def test_switched_off_losses_are_the_reference_placeholders():
+    """vaq / qav off: `tensor([0])` int64 on the model's device (llama/model.py:302), so that the summed loss has shape [1]."""
+    cfg = synth.preset("tiny", vaq=False, qav=False)
+    model, args = build_model(cfg, torch.float32)
+    vqa, vaq, qav = model(synth.make_batch(cfg, seed=3))
+    for z in (vaq, qav):
+        assert z.dtype == torch.int64 and tuple(z.shape) == (1,) and z.is_cuda and int(z) == 0
+    assert tuple((vqa + vaq + qav).shape) == (1,)
+
+
 def test_checkpoint_roundtrip(tmp_path):
     cfg, model, args, opt = _setup()
     scaler = misc.NativeScalerWithGradNormCount()

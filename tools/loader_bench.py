@@ -124,6 +124,40 @@ def main():
     print(f"training step ({a.model}{' ' + str(a.n_layers) + ' layers' if a.n_layers else ''}): fed by the producer "
           f"{fed:7.1f} samples/s, batches pre-staged in HBM {pre:7.1f} samples/s ({fed / pre * 100:.1f} %)")
 
+    # (c) the reference's own loop: engine.train_one_epoch (LR schedule, loss read back every iteration, meters)
+    import contextlib
+    import io
+    import engine
+
+    class Limited:                                   # the first n batches of the producer, with a length
+        def __init__(self, src, n):
+            self.src, self.n = src, n
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            for i, b in enumerate(self.src):
+                if i == self.n:
+                    return
+                yield b
+
+    margs.lr, margs.min_lr, margs.warmup_epochs, margs.epochs = 1e-3, 0.0, 0, 1
+    def epoch(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            engine.train_one_epoch(model, Limited(DeviceBatchProducer(loader, dev, depth=3), n), opt, 0, scaler,
+                                   args=margs)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    epoch(6)
+    t_short, t_long = epoch(a.steps), epoch(3 * a.steps)     # the difference leaves out the start of the loader's workers
+    loop = 2 * a.steps * a.batch_size / (t_long - t_short)
+    print(f"engine.train_one_epoch fed by the producer: {loop:7.1f} samples/s ({loop / pre * 100:.1f} % of the bare step; "
+          f"{a.steps} / {3 * a.steps} iterations took {t_short:.2f} / {t_long:.2f} s)")
+
 
 if __name__ == "__main__":
     main()

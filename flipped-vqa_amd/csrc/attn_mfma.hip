@@ -38,6 +38,15 @@ constexpr int LDR = DH + 8;             // row-major tile leading dim (bf16 elem
 constexpr int HP = DH / 2;              // rotation pairs per head
 constexpr float NEG_BIG = -1e30f;
 
+// Tuning builds (-DFVQA_ATTN_STAMPS): 100 MHz timestamps of each workgroup's phases in the fused backward kernel
+// (tools/attn_stamps.py); the shipping build compiles none of it.
+#ifdef FVQA_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[1024 * 16];
+#define AT_STAMP(slot) do { if (threadIdx.x == 0) g_attn_stamps[(size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 1023) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AT_STAMP(slot) do { } while (0)
+#endif
+
 // D[4g+r][lane&15] += sum_k X[4g+r][k] * Y[lane&15][k]
 __device__ __forceinline__ f32x4 mma(const uint4& x, const uint4& y, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, x), __builtin_bit_cast(bf16x8_t, y),
@@ -722,6 +731,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
   __shared__ float red[16];
   __shared__ int last_flag;
   const int h = blockIdx.x, n = blockIdx.y;
+  AT_STAMP(0);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
@@ -770,6 +780,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
   const float g2 = gate2[h];
   const int vs = vstart[n];
   __syncthreads();
+  AT_STAMP(1);
 
   float dg1 = 0.f, dg2 = 0.f;
   // ---- pass A: dQ of queries 16w..16w+15 (this lane: query r16, score-block column)
@@ -874,6 +885,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     }
   }
 
+  AT_STAMP(2);
   // ---- pass B: dK, dV of keys 16w..16w+15 (this lane: key r16; rows >= S are zero in LDS)
   f32x4 dk[8], dv[8];
 #pragma unroll
@@ -941,6 +953,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     }
   }
 
+  AT_STAMP(3);
   // ---- pass C: adapter keys (this lane: adapter row li), waves 4-7 take query group w-4
 #pragma unroll
   for (int d = 0; d < 8; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -992,6 +1005,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     for (int d = 0; d < 8; ++d) dk[d] = mma(t8[d], sf, dk[d]);
   }
   __syncthreads();                                        // pass B is done with sK / sV: reuse them
+  AT_STAMP(4);
   float* rK = reinterpret_cast<float*>(sK);               // [4][16][DH] fp32 (32 KiB <= one tile)
   float* rV = reinterpret_cast<float*>(sV);
   if (w >= 4) {
@@ -1033,6 +1047,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave: its write-through stores have completed
   __syncthreads();
+  AT_STAMP(5);
   if (threadIdx.x == 0) {
     const int old = __hip_atomic_fetch_add(arrive + h, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_flag = (old == n_seq - 1) ? 1 : 0;
@@ -1042,6 +1057,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     }
   }
   __syncthreads();
+  AT_STAMP(6);
   if (!last_flag) return;
   for (int idx = threadIdx.x; idx < A * DH; idx += 512) {
     const int aa = idx / DH, d = idx % DH;
@@ -1082,6 +1098,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     dgate2[h] += s2;
     __hip_atomic_store(arrive + h, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  AT_STAMP(7);
 }
 
 constexpr size_t FWD_LDS = (size_t)(2 * BQ + 32) * LDR * 2;
@@ -1095,6 +1112,17 @@ void allow_lds(K kernel, size_t bytes) {
 }
 
 }  // namespace
+
+#ifdef FVQA_ATTN_STAMPS
+extern "C" int fvqa_attn_stamps_read(unsigned long long* host, int clear) {
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) != hipSuccess) return -1;
+  if (clear) {
+    static unsigned long long zeros[1024 * 16];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), zeros, sizeof(zeros)) != hipSuccess) return -1;
+  }
+  return 1024 * 16;
+}
+#endif
 
 // launched from attn.hip's C entry points when dtype == bf16 (workspace layout shared with the vector build).
 // cos_t/sin_t != NULL: q and k in `qkv` are the raw projections and RoPE is applied on the fly.

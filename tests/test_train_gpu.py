@@ -1,6 +1,10 @@
 """engine.train_one_epoch / loss scaler / FusedAdamW end to end on the GPU (drop-in entry points of
 reference engine.py:10-56, util/misc.py:253-279, train.py:120-121)."""
+import json
 import math
+import os
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -253,3 +257,28 @@ def test_written_checkpoint_has_the_reference_layout(golden_dir, tmp_path):
             assert torch.is_tensor(v) and tuple(v.shape) == ref.shape and str(v.dtype).endswith(str(ref.dtype)), (i, k)
     assert set(ck["scaler"].keys()) == set(json.loads(str(g["scaler_json"])).keys())
     assert ck["epoch"] == 3
+
+
+def test_train_py_end_to_end_and_resume(tmp_path):
+    """`python train.py` with the reference's CLI (train.py:24-176) on synthetic batches: one epoch of the full-size 7B
+    (closed-form weights), log.txt + checkpoint_best.pth written as the reference writes them; a second run resumed from
+    that checkpoint continues at the next epoch with a lower loss."""
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flipped-vqa_amd")
+    env = dict(os.environ, FVQA_SYNTHETIC_TOKENIZER="1")
+    out = str(tmp_path / "run")
+    base = [sys.executable, "train.py", "--model", "7B", "--random_init", "--synthetic", "--synthetic_batches", "6",
+            "--batch_size", "4", "--max_seq_len", "128", "--warmup_epochs", "0", "--blr", "0.64", "--output_dir", out,
+            "--llama_model_path", str(tmp_path / "no_assets") + "/"]
+    r = subprocess.run(base + ["--epochs", "1"], cwd=pkg, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    log = [json.loads(x) for x in open(os.path.join(out, "log.txt"))]
+    assert len(log) == 1 and log[0]["epoch"] == 0 and math.isfinite(log[0]["train_loss"])
+    ck = torch.load(os.path.join(out, "checkpoint_best.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch", "scaler", "args"} and ck["epoch"] == 0
+    assert len(ck["model"]) == 3 + 2 * 32                    # trainables only, reference key names
+    r2 = subprocess.run(base + ["--epochs", "2", "--resume", os.path.join(out, "checkpoint_best.pth")], cwd=pkg, env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, (r2.stdout[-1500:], r2.stderr[-1500:])
+    log = [json.loads(x) for x in open(os.path.join(out, "log.txt"))]
+    assert [x["epoch"] for x in log] == [0, 1]               # resumed at start_epoch = 1
+    assert log[1]["train_loss"] < log[0]["train_loss"]

@@ -1,4 +1,4 @@
-// Main loop of the 256-row projection GEMM for gfx950 (shared by gemm256.hip and gemm_sk.hip).
+// Main loop of the 256-row projection GEMM for gfx950 (used by the persistent kernel in gemm_sk.hip).
 //
 // One call accumulates acc += A[m0.., k-range] x B[n0.., k-range]^T for one 256 x (64*NT) output tile over
 // `nw` WIDE stages (a wide stage = 128 bytes of K per row = 64 bf16 / 32 fp32 = two MFMA k-steps).

@@ -202,7 +202,9 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
   bf16_t* sV = sK + BQ * LDR;                             // [BQ][LDR]  V rows
   bf16_t* sKa = sV + BQ * LDR;                            // [16][LDR]  adapter K rows (zero beyond A)
   bf16_t* sVa = sKa + 16 * LDR;                           // [16][LDR]  adapter V rows
-  const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  // grid (H, n_seq, query blocks), LAST query block first: under the causal mask block qb walks qb + 1 key tiles, and the
+  // dispatcher hands out workgroups in grid order — longest first keeps the short ones for filling the tail
+  const int h = blockIdx.x, n = blockIdx.y, qb = (int)gridDim.z - 1 - (int)blockIdx.z;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
@@ -363,7 +365,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   bf16_t* sKa = sV + BQ * LDR;                            // [16][LDR]
   bf16_t* sVa = sKa + 16 * LDR;                           // [16][LDR]
   __shared__ float red[16];
-  const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  // grid (H, n_seq, query blocks), LAST query block first: under the causal mask block qb walks qb + 1 key tiles, and the
+  // dispatcher hands out workgroups in grid order — longest first keeps the short ones for filling the tail
+  const int h = blockIdx.x, n = blockIdx.y, qb = (int)gridDim.z - 1 - (int)blockIdx.z;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int D = H * DH;
@@ -515,14 +519,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   const float b1 = block_sum_512(dg1, red);
   const float b2 = block_sum_512(dg2, red + 8);
   if (threadIdx.x == 0) {
-    const size_t pidx = (((size_t)n * H + h) * gridDim.x + qb) * 2;
+    const size_t pidx = (((size_t)n * H + h) * gridDim.z + qb) * 2;
     gate_part[pidx] = b1;
     gate_part[pidx + 1] = b2;
   }
 }
 
 // ------------------------------------------------------------------------------- backward: dK, dV
-// blockIdx.x < nkb: 128 text keys (16 per wave); blockIdx.x == nkb: the adapter keys (one 16-key block;
+// kb < nkb: 128 text keys (16 per wave); kb == nkb: the adapter keys (one 16-key block;
 // waves 0-3 take the 32-query groups g ≡ w of every query tile and their partial sums meet in LDS).
 template <bool ROPE>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
@@ -536,7 +540,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   bf16_t* sdO = sQ + BQ * LDR;                            // [BQ][LDR] dO rows: row reads for dP, column reads for dOᵀ·P
   float* sL = reinterpret_cast<float*>(sdO + BQ * LDR);   // [BQ] lse, [BQ] delta of the staged queries
   float* sDl = sL + BQ;
-  const int kb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  // grid (H, n_seq, key blocks + 1), longest first: the adapter block (kb == nkb: every query), then key block 0, 1, ...
+  const int h = blockIdx.x, n = blockIdx.y, kb = blockIdx.z == 0 ? (int)gridDim.z - 1 : (int)blockIdx.z - 1;
   const bool adapter = kb == nkb;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, li = lane & 15;
@@ -1139,10 +1144,10 @@ int fvqa_attn_fwd_mfma(const void* qkv, void* o, float* lse_a, float* lse_t, con
     attr = true;
   }
   if (cos_t)
-    hipLaunchKernelGGL(attn_fwd_mfma_k<true>, dim3(nqb, H, n_seq), dim3(512), FWD_LDS, st, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(attn_fwd_mfma_k<true>, dim3(H, n_seq, nqb), dim3(512), FWD_LDS, st, (const bf16_t*)qkv,
                        (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, n_seq, S, H, A, F);
   else
-    hipLaunchKernelGGL(attn_fwd_mfma_k<false>, dim3(nqb, H, n_seq), dim3(512), FWD_LDS, st, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(attn_fwd_mfma_k<false>, dim3(H, n_seq, nqb), dim3(512), FWD_LDS, st, (const bf16_t*)qkv,
                        (bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, n_seq, S, H, A, F);
   return 0;
 }
@@ -1176,10 +1181,10 @@ int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const fl
     return 1;
   }
 #define FVQA_BWD(R)                                                                                                   \
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_k<R>, dim3(nqb, H, n_seq), dim3(512), FWD_LDS, st, (const bf16_t*)d_o,           \
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_k<R>, dim3(H, n_seq, nqb), dim3(512), FWD_LDS, st, (const bf16_t*)d_o,           \
                      (const bf16_t*)qkv, (const bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t,          \
                      (bf16_t*)dqkv, delta_a, delta_t, gate_part, n_seq, S, H, A, F);                                  \
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_k<R>, dim3(nqb + 1, H, n_seq), dim3(512), DKV_LDS, st, (const bf16_t*)d_o,      \
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_k<R>, dim3(H, n_seq, nqb + 1), dim3(512), DKV_LDS, st, (const bf16_t*)d_o,      \
                      (const bf16_t*)qkv, lse_a, lse_t, delta_a, delta_t, gate1, gate2, vstart, cos_t, sin_t,          \
                      (bf16_t*)dqkv, dka, dva, n_seq, S, H, A, F, nqb);
   if (cos_t) { FVQA_BWD(true) } else { FVQA_BWD(false) }

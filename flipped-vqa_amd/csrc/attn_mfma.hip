@@ -252,7 +252,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
     }
     __syncthreads();
     const int jlast = min(i0 + 15, S - 1) - kt * BQ;      // last tile-local key any row of this wave sees
-    const int ng = jlast < 0 ? 0 : min(4, (jlast >> 5) + 1);
+    // (a wave whose 16 queries all lie beyond S — the ragged last block — only takes part in the staging)
+    const int ng = (jlast < 0 || i0 >= S) ? 0 : min(4, (jlast >> 5) + 1);
     for (int gq = 0; gq < ng; ++gq) {                     // 32 keys = two 16-key score blocks = one P·V k-step
       uint4 kfr[2][4];
       group_frags(sK, 32 * gq, lane, kfr);
@@ -466,7 +467,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
       __syncthreads();
     }
     const int jlast = min(i0 + 15, S - 1) - kt * BQ;
-    const int ng = jlast < 0 ? 0 : min(4, (jlast >> 5) + 1);
+    // (a wave whose 16 queries all lie beyond S — the ragged last block — only takes part in the staging)
+    const int ng = (jlast < 0 || i0 >= S) ? 0 : min(4, (jlast >> 5) + 1);
     for (int gq = 0; gq < ng; ++gq) {
       uint4 kfr[2][4], vfr[2][4];
       group_frags(sK, 32 * gq, lane, kfr);
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
     int gbeg, gend, gstep;
     const int gmax = min(4, (min(S, (t + 1) * BQ) - t * BQ + 31) >> 5);          // groups holding real queries
     if (adapter) { gbeg = w; gend = w < 4 ? gmax : 0; gstep = 4; }
-    else { gbeg = (t == kb) ? (w >> 1) : 0; gend = gmax; gstep = 1; }
+    else { gbeg = (t == kb) ? (w >> 1) : 0; gend = j0 < S ? gmax : 0; gstep = 1; }     // (no work for a wave of keys beyond S)
     for (int gq = gbeg; gq < gend; gq += gstep) {
       uint4 qfr[2][4], ofr[2][4];
       group_frags(sQ, 32 * gq, lane, qfr);

@@ -70,6 +70,9 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
         if getattr(args, "debug", False):
             break
 
+    eng = getattr(getattr(model, "module", model), "_engine", None)
+    if eng is not None:
+        eng.check_gemm_error()                                # one small read per epoch (include/fvqa.h: error word)
     log.synchronize_between_processes()
     print("Averaged stats:", log)
     return {k: m.global_avg for k, m in log.meters.items()}

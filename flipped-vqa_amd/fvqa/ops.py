@@ -74,6 +74,16 @@ def gemm_workspace(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+def gemm_error(ws: Optional[torch.Tensor] = None, device=None) -> int:
+    """The error word of a persistent-GEMM workspace (include/fvqa.h: non-zero after a launch whose split-K exchange
+    timed out). Default: the shared per-device workspace of this module. One device->host read."""
+    if ws is None:
+        ws = _GEMM_WS.get(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        if ws is None:
+            return 0
+    return int(ws[:8].view(torch.int64)[0].item())
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
             tail: Optional[torch.Tensor] = None, m_split: int = 0, variant: int = 0) -> torch.Tensor:
     """out[M,N] = a[M,K] @ b[N,K]^T (+ residual). Rows >= m_split go to `tail` (fp32) when given."""

@@ -222,6 +222,18 @@ class StepEngine:
         return self._vstart[key]
 
     # ------------------------------------------------------------------ forward
+    def check_gemm_error(self):
+        """Raise if any persistent-GEMM launch of this engine reported a timed-out split-K exchange (the error word of
+        its workspaces, include/fvqa.h). One small device->host read per workspace: call it at an epoch boundary."""
+        bad = ops.gemm_error(device=self.device)
+        for ar in list(self._arena.values()) + list(self._gen_arena.values()):
+            ws = getattr(ar, "plan_ws", None)
+            if ws is not None:
+                bad |= ops.gemm_error(ws)
+        if bad:
+            raise RuntimeError("fvqa: a split-K exchange of the persistent GEMM timed out (workspace error word "
+                               f"{bad}); the results of that step are invalid")
+
     def forward(self, data: dict):
         m, pk = self.model, self.pack
         dev = self.device

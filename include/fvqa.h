@@ -75,7 +75,9 @@ int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab, void* z, i
 /* fvqa_gemm_workspace: bytes of `workspace` the kernel variant 0 picks for the problem needs (0: none).
  * Its FIRST 4096 BYTES are the epoch flags of the persistent kernel (csrc/gemm_sk.hip): the caller zeroes them ONCE
  * after allocating the buffer (256-byte aligned); no call ever needs them reset. One workspace serves one stream at
- * a time. */
+ * a time. The first 64-bit word is an ERROR word: a workgroup whose bounded wait (~1 s) for a partner of a split tile
+ * ran out sets it to non-zero and lets the grid drain — the outputs of that launch are then invalid; callers read it
+ * back at a convenient point (fvqa.ops.gemm_error / StepEngine.check_gemm_error do). */
 size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
 /* The persistent kernel (variant 0 for M >= 192, N >= 256, N % 8 == 0, no tail rows; variant 13 forces it): a grid of
  * at most one workgroup per CU walks whole 256x256 output tiles, or — outputs with few tiles — one K range of a tile

@@ -599,3 +599,17 @@ def test_grad_norm_and_adamw_match_torch():
     ops.adamw_step(flat, grad2, m, v, 0.05, 0.9, 0.95, 1e-8, 0.14, step, found)
     ops.scaler_update(step, sc, tracker, found, 2.0, 0.5, 2)
     assert torch.equal(flat, before) and step.item() == 3.0 and sc.item() == scale
+
+
+def test_gemm_error_word_is_read_back_and_reported():
+    """The first word of a persistent-GEMM workspace is its error word (include/fvqa.h): zero after ordinary launches;
+    a non-zero word makes the engine's check raise."""
+    a, b = rnd(1024, 4096, dtype=torch.bfloat16, seed=1), rnd(4096, 4096, dtype=torch.bfloat16, scale=1 / 64, seed=2)
+    out = torch.empty(1024, 4096, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out)                        # N = 4096: split 4 ways, reduced inside the launch
+    torch.cuda.synchronize()
+    assert ops.gemm_error(device=out.device) == 0
+    ws = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    assert ops.gemm_error(ws) == 0
+    ws[:8].view(torch.int64)[0] = 1
+    assert ops.gemm_error(ws) == 1

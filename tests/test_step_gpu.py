@@ -46,6 +46,7 @@ def test_fp32_step_matches_reference_golden(case):
     print(case, {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
     # the fp32 build is in fact far inside the bar
     assert rep["loss_vqa"] < 1e-4
+    model._engine.check_gemm_error()                         # no split-K exchange of the persistent GEMM timed out
     _free(model)
 
 
@@ -63,6 +64,7 @@ def test_bf16_step_against_reference_golden(case):
     losses, grads, logits, layer_out = run_step(model, batch)
     rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=BF16_LOSS_RTOL, tol=BF16_TOL)
     print(case, {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
+    model._engine.check_gemm_error()
     _free(model)
 
 

@@ -250,9 +250,10 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
                             int variant, void* workspace, size_t workspace_bytes, void* stream) {
   if (!A || !B || (!C && !(tail && m_split == 0))) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype) || !fvqa_dtype_ok(out_dtype)) return FVQA_EINVAL;
-  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_SWIGLU_BWD) return FVQA_EINVAL;
-  if ((epilogue == FVQA_EPI_RESIDUAL || epilogue == FVQA_EPI_SWIGLU_BWD) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
-  if (epilogue == FVQA_EPI_SWIGLU_BWD && (tail || ldc != 2 * N)) return FVQA_EINVAL;
+  const bool swb = epilogue == FVQA_EPI_SWIGLU_BWD || epilogue == FVQA_EPI_SWIGLU_BWD_ST;
+  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && !swb) return FVQA_EINVAL;
+  if ((epilogue == FVQA_EPI_RESIDUAL || swb) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
+  if (swb && (tail || ldc != 2 * N)) return FVQA_EINVAL;
   if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
   if (variant != 0 && variant != 1 && variant != 2 && variant != 12 && variant != 13) return FVQA_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return FVQA_ESHAPE;
@@ -267,10 +268,10 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
                      (((uintptr_t)C | (uintptr_t)R) & 15) == 0 && workspace != nullptr &&
                      ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace();
   if (variant == 13 && !sk_ok) return FVQA_EALIGN;
-  if (variant == 13 || (variant == 0 && sk_ok && ((M >= 192 && N >= 256) || epilogue == FVQA_EPI_SWIGLU_BWD)))
+  if (variant == 13 || (variant == 0 && sk_ok && ((M >= 192 && N >= 256) || swb)))
     return fvqa_gemm_sk_impl(A, B, C, R, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, dtype, out_dtype, epilogue, st,
                              nullptr, nullptr);
-  if (epilogue == FVQA_EPI_SWIGLU_BWD) return FVQA_EALIGN;    // that epilogue lives in the persistent kernel only
+  if (swb) return FVQA_EALIGN;                                // that epilogue lives in the persistent kernel only
   // every row goes to the fp32 tail (m_split == 0): the decode-shape kernel accumulates straight into it
   if (dtype == FVQA_BF16 && M <= 16 && (K % 256) == 0 && tail != nullptr && m_split == 0 && epilogue == FVQA_EPI_NONE &&
       (variant == 0 || variant == 12))
@@ -302,16 +303,17 @@ extern "C" int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const v
                                   const fvqa_sk_rider* rider, void* workspace, size_t workspace_bytes, void* stream) {
   if (!rider || !rider->A || !rider->B || !rider->C || rider->M <= 0 || rider->N <= 0 || rider->K <= 0) return FVQA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const bool swb = epilogue == FVQA_EPI_SWIGLU_BWD || epilogue == FVQA_EPI_SWIGLU_BWD_ST;
   const bool sk_ok = A && B && C && fvqa_dtype_ok(dtype) && (N & 7) == 0 && (ldc & 7) == 0 &&
                      (((uintptr_t)C | (uintptr_t)R) & 15) == 0 && workspace != nullptr &&
                      ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace() &&
-                     ((M >= 192 && N >= 256) || epilogue == FVQA_EPI_SWIGLU_BWD);
+                     ((M >= 192 && N >= 256) || swb);
   int rode = 0;
   int rc;
   if (sk_ok) {
-    if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_SWIGLU_BWD) return FVQA_EINVAL;
-    if ((epilogue == FVQA_EPI_RESIDUAL || epilogue == FVQA_EPI_SWIGLU_BWD) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
-    if (epilogue == FVQA_EPI_SWIGLU_BWD && ldc != 2 * N) return FVQA_EINVAL;
+    if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && !swb) return FVQA_EINVAL;
+    if ((epilogue == FVQA_EPI_RESIDUAL || swb) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
+    if (swb && ldc != 2 * N) return FVQA_EINVAL;
     if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
     const int ke = dtype == FVQA_BF16 ? 64 : 32;
     const size_t es = fvqa_dtype_size(dtype);
@@ -331,9 +333,8 @@ extern "C" int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const v
                       rider->ldc, rider->M, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
 }
 
-extern "C" int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K,
-                                       int lda, int ldb, int dtype, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+static int swiglu_fwd_impl(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K, int lda, int ldb,
+                           int dtype, void* workspace, size_t workspace_bytes, void* stream, int epilogue) {
   if (!A || !B13 || !ab || !z || !fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
   const int N = 2 * hidden;
   const int ke = dtype == FVQA_BF16 ? 64 : 32;
@@ -344,5 +345,19 @@ extern "C" int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab,
       workspace_bytes < fvqa_gemm_sk_workspace())
     return FVQA_EALIGN;
   return fvqa_gemm_sk_impl(A, B13, ab, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, N, dtype, dtype,
-                           FVQA_EPI_SWIGLU_FWD, (hipStream_t)stream, nullptr, nullptr, z);
+                           epilogue, (hipStream_t)stream, nullptr, nullptr, z);
+}
+
+extern "C" int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K,
+                                       int lda, int ldb, int dtype, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  return swiglu_fwd_impl(A, B13, ab, z, M, hidden, K, lda, ldb, dtype, workspace, workspace_bytes, stream,
+                         FVQA_EPI_SWIGLU_FWD);
+}
+
+extern "C" int fvqa_gemm_nt_swiglu_fwd_st(const void* A, const void* B13, void* st, void* z, int M, int hidden, int K,
+                                          int lda, int ldb, int dtype, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  return swiglu_fwd_impl(A, B13, st, z, M, hidden, K, lda, ldb, dtype, workspace, workspace_bytes, stream,
+                         FVQA_EPI_SWIGLU_FWD_ST);
 }

@@ -122,13 +122,14 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
     auto live = [&](int t) { return 4 * p + (t >> 1) < n_own; };
     auto grow = [&](int t) { return m0 + wr * 128 + ((p * 64 + row_of(t)) ^ rowxor); };     // output row
     uint4 qa[8], qb[8];
-    if constexpr (sizeof(T) == 2 && (EPI == FVQA_EPI_SWIGLU_BWD || EPI == FVQA_EPI_RESIDUAL)) {
+    constexpr bool SWB = EPI == FVQA_EPI_SWIGLU_BWD || EPI == FVQA_EPI_SWIGLU_BWD_ST;
+    if constexpr (sizeof(T) == 2 && (SWB || EPI == FVQA_EPI_RESIDUAL)) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {                                   // epilogue operands in flight before the staging
         const int m = grow(t);
         qa[t] = qb[t] = uint4{0u, 0u, 0u, 0u};
         if (live(t) && m < M && nA < N) {
-          if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
+          if constexpr (SWB) {
             const T* rp = R + (size_t)m * ldc + ab16(nA);             // ab rows (AB16): a block, b block 16 columns on
             qa[t] = *reinterpret_cast<const uint4*>(rp);
             qb[t] = *reinterpret_cast<const uint4*>(rp + 16);
@@ -159,8 +160,10 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
       if (!live(t) || m >= M) continue;
       float(&vA)[4] = reinterpret_cast<float(&)[4]>(v[0]);
       float(&vB)[4] = reinterpret_cast<float(&)[4]>(v[4]);
-      if constexpr (EPI == FVQA_EPI_SWIGLU_BWD) {
+      if constexpr (SWB) {
         // v = dz[m][n..]; R = ab, C = dab (rows of 2N in the AB16 layout): d(silu(a)*b)   (llama/model.py:142 backward)
+        // _ST: R holds s = silu(a) and t = d z / d a = b sigma(a) (1 + a (1 - sigma(a))) in the a and b slots (left there by
+        // the forward's FVQA_EPI_SWIGLU_FWD_ST epilogue), so da = dz * t and db = dz * s
         const size_t o = (size_t)m * ldc;
         constexpr int hb_ = 16;                                       // b sits 16 columns after a
         const int nA_ = (int)ab16(nA), nB_ = (int)ab16(nB);
@@ -177,9 +180,14 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float sg = 1.f / (1.f + __expf(-a_[e]));
-          da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
-          db[e] = v[e] * a_[e] * sg;
+          if constexpr (EPI == FVQA_EPI_SWIGLU_BWD_ST) {
+            da[e] = v[e] * b_[e];
+            db[e] = v[e] * a_[e];
+          } else {
+            const float sg = 1.f / (1.f + __expf(-a_[e]));
+            da[e] = v[e] * b_[e] * sg * (1.f + a_[e] * (1.f - sg));
+            db[e] = v[e] * a_[e] * sg;
+          }
         }
         if constexpr (sizeof(TO) == 2) {
           *reinterpret_cast<uint4*>(C + o + nA_) = pack8(da);
@@ -224,7 +232,7 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
 // are a-blocks and j = 1, 3 the matching b-blocks: z = silu(a) * b (llama/model.py:142) is formed lane by lane from the
 // values ROUNDED to the storage type (what the separate kernel reads back from `ab`), staged through the wave's LDS like
 // the tile itself and stored as 64-byte row segments: 128 rows x 32 z columns per wave.
-template <typename T>
+template <typename T, bool ST>
 __device__ __forceinline__ void store_swiglu(f32x4 (&acc)[8][4], char* smem, const SkArgs& a, int m0, int n0, int w,
                                              int lane, int n_own, int rowxor) {
   const int wr = w >> 2, wc = w & 3;
@@ -245,7 +253,17 @@ __device__ __forceinline__ void store_swiglu(f32x4 (&acc)[8][4], char* smem, con
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float av = round_to<T>(acc[p * 4 + ii][2 * jz][e]), bv = round_to<T>(acc[p * 4 + ii][2 * jz + 1][e]);
-          z[e] = round_to<T>(av / (1.f + __expf(-av))) * bv;
+          if constexpr (ST) {
+            // what the backward needs is not (a, b) but s = silu(a) (d z / d b) and t = d z / d a: they take the a and b
+            // slots of the tile, which store_tile writes AFTER this pass (the SwiGLU' epilogue is then two multiplies)
+            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-av));
+            const float sv = round_to<T>(av * sg);
+            z[e] = sv * bv;
+            acc[p * 4 + ii][2 * jz][e] = sv;
+            acc[p * 4 + ii][2 * jz + 1][e] = bv * sg * (1.f + av * (1.f - sg));
+          } else {
+            z[e] = round_to<T>(av / (1.f + __expf(-av))) * bv;
+          }
         }
         // row (ii*16 + crow) of the pass, z columns jz*16 + 4*(lane>>4) ..+3; chunk c of a row sits at c ^ (row & 7)
         *reinterpret_cast<f32x4*>(stg + (ii * 16 + crow) * 32 + (((jz * 4 + (lane >> 4)) ^ (crow & 7)) << 2)) = z;
@@ -295,8 +313,8 @@ __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs
   const int ts = a.plan.ts;
   if (tid == 0) {
     __hip_atomic_store(a.sync + 1 + wid, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int p = 0; p < NP; ++p)
-      if (p != c) (void)wait_epoch(a.sync + 1 + (team0 + p * pstride) * ts + jm, a.epoch, a.sync);
+    for (int p = 0; p < NP; ++p)        // (a lost partner has raised the error word: the others are not waited for)
+      if (p != c && !wait_epoch(a.sync + 1 + (team0 + p * pstride) * ts + jm, a.epoch, a.sync)) break;
 #ifdef FVQA_SK_ACQUIRE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // not needed while EVERY load of a partner's slab is an sc1 load
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -389,7 +407,10 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
     SK_STAMP(4);
     if constexpr (EPI == FVQA_EPI_SWIGLU_FWD) {
       store_tile<T, TO, FVQA_EPI_NONE>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);      // ab (saved for the backward)
-      store_swiglu<T>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);                        // z
+      store_swiglu<T, false>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);                 // z
+    } else if constexpr (EPI == FVQA_EPI_SWIGLU_FWD_ST) {
+      store_swiglu<T, true>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);                  // z; acc <- (s, t)
+      store_tile<T, TO, FVQA_EPI_NONE>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);      // st (saved for the backward)
     } else {
       store_tile<T, TO, EPI>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);
     }
@@ -416,16 +437,18 @@ int launch_sk(const SkArgs& a, hipStream_t st) {
   return FVQA_OK;
 }
 
-int cu_count() {
-  static std::atomic<int> n{0};
-  int v = n.load();
-  if (v > 0) return v;
+int cu_count() {                                          // of the CURRENT device (cached per device id)
+  constexpr int MAXDEV = 64;
+  static std::atomic<int> n[MAXDEV];
   int dev = 0;
-  hipDeviceProp_t pr;
-  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return 256;
+  const int v = n[dev].load();
+  if (v > 0) return v;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return 256;                                           // MI355X; also what the host-only plan queries assume
-  n.store(pr.multiProcessorCount);
-  return pr.multiProcessorCount;
+  n[dev].store(cus);
+  return cus;
 }
 
 }  // namespace
@@ -468,10 +491,16 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
                       const fvqa_sk_rider* rider, int* rode, void* C2) {
   if (rode) *rode = 0;
   if (!ws || ws_bytes < fvqa_gemm_sk_workspace() || ((uintptr_t)ws & 255)) return FVQA_EALIGN;
+  {
+    // the launch epoch is a host-side kernel argument: a captured launch would be replayed with a stale epoch, its
+    // partners' flags would already match and partial tiles would race — refuse instead of corrupting silently
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return FVQA_EINVAL;
+  }
   const int n_cu = cu_count();
   SkArgs a;
   a.A = A; a.B = B; a.C = C; a.R = R; a.C2 = C2;
-  if (epilogue == FVQA_EPI_SWIGLU_FWD && (!C2 || (N & 31) || ((uintptr_t)C2 & 15) || out_dtype != dtype)) return FVQA_EINVAL;
+  if ((epilogue == FVQA_EPI_SWIGLU_FWD || epilogue == FVQA_EPI_SWIGLU_FWD_ST) && (!C2 || (N & 31) || ((uintptr_t)C2 & 15) || out_dtype != dtype)) return FVQA_EINVAL;
   a.sync = (u64*)ws;
   a.slabs = (float*)((char*)ws + SYNC_BYTES);
   a.stamps = (u64*)((char*)ws + SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float));
@@ -495,6 +524,8 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     case FVQA_EPI_RESIDUAL: return launch_sk<T, TO, FVQA_EPI_RESIDUAL>(a, st);                \
     case FVQA_EPI_SWIGLU_BWD: return launch_sk<T, TO, FVQA_EPI_SWIGLU_BWD>(a, st);            \
     case FVQA_EPI_SWIGLU_FWD: return launch_sk<T, TO, FVQA_EPI_SWIGLU_FWD>(a, st);            \
+    case FVQA_EPI_SWIGLU_BWD_ST: return launch_sk<T, TO, FVQA_EPI_SWIGLU_BWD_ST>(a, st);      \
+    case FVQA_EPI_SWIGLU_FWD_ST: return launch_sk<T, TO, FVQA_EPI_SWIGLU_FWD_ST>(a, st);      \
     default: return FVQA_EINVAL;                                                              \
   }
   if (dtype == FVQA_BF16) {

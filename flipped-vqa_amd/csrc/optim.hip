@@ -12,11 +12,14 @@ constexpr int NB = 256;  // partial blocks per segment (the largest segment, vis
 // aligned body of a segment, scalars on its ragged ends; a block's elements and their order are fixed, so the norm is
 // bitwise repeatable.
 __global__ __launch_bounds__(256) void unscale_sq_k(float* __restrict__ grad, const int64_t* __restrict__ seg_off,
-                                                    const float* __restrict__ scale, float* __restrict__ part) {
+                                                    const float* __restrict__ scale, float grad_div,
+                                                    float* __restrict__ part) {
   __shared__ float red[4];
   const int seg = blockIdx.y;
   const int64_t lo = seg_off[seg], hi = seg_off[seg + 1];
-  const float inv = 1.f / scale[0];
+  // grad_div: the number of replicas whose gradients were SUMMED into `grad` (the data-parallel mean rides here instead
+  // of in a pass of its own; exact for power-of-two world sizes and loss scales)
+  const float inv = 1.f / (scale[0] * grad_div);
   float sq = 0.f, bad = 0.f;
   auto one = [&](int64_t i) {
     const float g = grad[i] * inv;
@@ -48,9 +51,13 @@ __global__ __launch_bounds__(256) void unscale_sq_k(float* __restrict__ grad, co
 }
 
 // one thread per segment sums its NB partials in fixed order; thread 0 then forms the total norm
+// gemm_err (may be NULL): the error word of the persistent GEMM's workspace (include/fvqa.h). Non-zero = a split-K
+// exchange of some launch of this step timed out and its outputs are garbage: the step is skipped exactly like an
+// overflow (found_inf = 2 tells the host which of the two it was) — no extra device->host read on the step's path.
 __global__ __launch_bounds__(256) void norm_finish_k(const float* __restrict__ part, int n_seg,
                                                      float* __restrict__ seg_sq, float* __restrict__ found_inf,
-                                                     float* __restrict__ total_norm) {
+                                                     float* __restrict__ total_norm,
+                                                     const unsigned long long* __restrict__ gemm_err) {
   __shared__ float red[4];
   float tot = 0.f, bad = 0.f;
   for (int s = threadIdx.x; s < n_seg; s += 256) {
@@ -66,7 +73,10 @@ __global__ __launch_bounds__(256) void norm_finish_k(const float* __restrict__ p
   bad = block_sum_256(bad, red);
   if (threadIdx.x == 0) {
     total_norm[0] = sqrtf(tot);
-    found_inf[0] = (bad > 0.f || !isfinite(tot)) ? 1.f : 0.f;
+    float f = (bad > 0.f || !isfinite(tot)) ? 1.f : 0.f;
+    if (gemm_err != nullptr &&
+        __hip_atomic_load(gemm_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) f = 2.f;
+    found_inf[0] = f;
   }
 }
 
@@ -111,15 +121,16 @@ __global__ void scaler_update_k(float* __restrict__ step, float* __restrict__ sc
 extern "C" size_t fvqa_grad_norm_workspace(int n_seg) { return (size_t)(n_seg > 0 ? n_seg : 0) * NB * 2 * sizeof(float); }
 
 extern "C" int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n_seg, const float* scale,
-                                      float* seg_sq, float* found_inf, float* total_norm, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+                                      float grad_div, const void* gemm_err, float* seg_sq, float* found_inf,
+                                      float* total_norm, void* workspace, size_t workspace_bytes, void* stream) {
   if (!grad || !seg_off || !scale || !seg_sq || !found_inf || !total_norm || !workspace) return FVQA_EINVAL;
+  if (!(grad_div >= 1.f) || ((uintptr_t)gemm_err & 7)) return FVQA_EINVAL;
   if (n_seg <= 0 || n_seg > 65535) return FVQA_ESHAPE;
   if (workspace_bytes < fvqa_grad_norm_workspace(n_seg)) return FVQA_EALIGN;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(unscale_sq_k, dim3(NB, n_seg), dim3(256), 0, st, grad, seg_off, scale, (float*)workspace);
+  hipLaunchKernelGGL(unscale_sq_k, dim3(NB, n_seg), dim3(256), 0, st, grad, seg_off, scale, grad_div, (float*)workspace);
   hipLaunchKernelGGL(norm_finish_k, dim3(1), dim3(256), 0, st, (const float*)workspace, n_seg, seg_sq, found_inf,
-                     total_norm);
+                     total_norm, (const unsigned long long*)gemm_err);
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
@@ -146,5 +157,5 @@ extern "C" int fvqa_scaler_update(float* step, float* scale, float* growth_track
   return FVQA_OK;
 }
 
-extern "C" int fvqa_version(void) { return 9; }
+extern "C" int fvqa_version(void) { return 10; }
 extern "C" const char* fvqa_arch(void) { return "gfx950"; }

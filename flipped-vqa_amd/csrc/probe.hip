@@ -7,7 +7,8 @@ std::atomic<FvqaProbe*> g_probe{nullptr};
 
 void drop(FvqaProbe* p) {
   if (!p) return;
-  for (auto& r : p->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto& r : p->recs)
+    if (r.timed) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   delete p;
 }
 }  // namespace
@@ -16,7 +17,9 @@ FvqaProbe* fvqa_probe_current() { return g_probe.load(std::memory_order_acquire)
 
 // (the caller makes sure no launch is in flight on another host thread while it switches the probe)
 extern "C" int fvqa_gemm_timing_enable(int on) {
-  drop(g_probe.exchange(on ? new FvqaProbe() : nullptr));
+  FvqaProbe* p = nullptr;
+  if (on > 0) { p = new FvqaProbe(); p->stride = on; }
+  drop(g_probe.exchange(p));
   return FVQA_OK;
 }
 
@@ -28,15 +31,15 @@ extern "C" int fvqa_gemm_timing_read(int max, float* us, double* flops, int* kin
   if (max <= 0) return n;                               // size query: record untouched
   for (int i = 0; i < n; ++i) {
     FvqaProbeRec& r = p->recs[i];
-    float ms = 0.f;
-    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+    float ms = -2e-3f;                                  // (-2 us: launch counted, not bracketed)
+    if (r.timed && (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess))
+      ms = -1e-3f;
     if (i < max) {
       if (us) us[i] = ms * 1e3f;
       if (flops) flops[i] = r.flops;
       if (kind) kind[i] = r.kind;
     }
-    (void)hipEventDestroy(r.e0);
-    (void)hipEventDestroy(r.e1);
+    if (r.timed) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   }
   p->recs.clear();
   return n;

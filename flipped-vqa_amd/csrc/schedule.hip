@@ -15,6 +15,7 @@
 //        -> QKV^T GEMM on the sequence rows -> RMSNorm' (+residual grad); the adapter rows of dqkv go through the
 //        decode-shape kernel straight into the fp32 adapter-query gradient (+=)
 #include "common.h"
+#include <cstdlib>
 
 extern "C" size_t fvqa_layers_gemm_workspace(const fvqa_layer_plan* p);
 extern "C" size_t fvqa_gemm_sk_workspace(void);
@@ -29,6 +30,13 @@ inline const char* at(const void* base, size_t elems, size_t esize) { return (co
     int rc__ = (call);       \
     if (rc__) return rc__;   \
   } while (0)
+
+// tuning switch (same-box A/B): FVQA_SWIGLU_AB=1 keeps a and b in the `ab` buffer and the full SwiGLU' arithmetic in the
+// W2^T epilogue (the round-2 form); default: the (s, t) pair of FVQA_EPI_SWIGLU_FWD_ST / _BWD_ST
+bool swiglu_st() {
+  static const bool v = [] { const char* e = getenv("FVQA_SWIGLU_AB"); return !(e && e[0] == '1'); }();
+  return v;
+}
 
 int check_plan_dims_only(const fvqa_layer_plan* p) {
   if (!p) return FVQA_EINVAL;
@@ -115,8 +123,11 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     RUN(fvqa_gemm_nt(o, p->wo[i], h, x, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
                      p->gemm_ws_bytes, stream));
     RUN(fvqa_rmsnorm_fwd(h, p->fn[i], p->hn, p->rstd2 + (size_t)i * R, R, D, p->eps, dt, stream));
-    // ab = hn·(W1|W3)^T and z = silu(a)*b (model.py:142) in one launch
-    RUN(fvqa_gemm_nt_swiglu_fwd(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
+    // z = silu(a)*b with (a | b) = hn·(W1|W3)^T (model.py:142) in one launch; `ab` keeps the backward's factors (s, t)
+    if (swiglu_st())
+      RUN(fvqa_gemm_nt_swiglu_fwd_st(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
+    else
+      RUN(fvqa_gemm_nt_swiglu_fwd(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
     // x_next = h + z·W2^T (model.py:186), then the next layer's attention norm (or the final norm)
     RUN(fvqa_gemm_nt(p->z, p->w2[i], x_next, h, nullptr, R, D, Hf, Hf, Hf, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
@@ -143,6 +154,7 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
   void* nxt = p->dnxt;
   void* t = p->dz;                                     // (R, D) scratch for the GEMM outputs that feed the norm backward
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
+  const int epi_sw = swiglu_st() ? FVQA_EPI_SWIGLU_BWD_ST : FVQA_EPI_SWIGLU_BWD;
   RUN(fvqa_rmsnorm_bwd(dxnf, at(p->xs, (size_t)L * R * D, es), p->norm_w, p->rstdN, nullptr, cur, R, D, dt, stream));
   for (int i = L - 1; i >= 0; --i) {
     const void* x = at(p->xs, (size_t)i * R * D, es);
@@ -156,10 +168,10 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     // gradient rows of the layer walked just before (dqkv still holds that layer's [0, dK_a, dV_a] rows)
     if (i + 1 < L) {
       const fvqa_sk_rider ga = adapter_grad_rider(p, i + 1);
-      RUN(fvqa_gemm_nt_rider(cur, p->w2_t[i], p->dab, ab, R, Hf, D, D, D, 2 * Hf, dt, dt, FVQA_EPI_SWIGLU_BWD, &ga,
+      RUN(fvqa_gemm_nt_rider(cur, p->w2_t[i], p->dab, ab, R, Hf, D, D, D, 2 * Hf, dt, dt, epi_sw, &ga,
                              p->gemm_ws, p->gemm_ws_bytes, stream));
     } else {
-      RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dab, ab, nullptr, R, Hf, D, D, D, 2 * Hf, R, dt, dt, FVQA_EPI_SWIGLU_BWD, 0,
+      RUN(fvqa_gemm_nt(cur, p->w2_t[i], p->dab, ab, nullptr, R, Hf, D, D, D, 2 * Hf, R, dt, dt, epi_sw, 0,
                        p->gemm_ws, p->gemm_ws_bytes, stream));
     }
     RUN(fvqa_gemm_nt(p->dab, p->w13_t[i], t, nullptr, nullptr, R, D, 2 * Hf, 2 * Hf, 2 * Hf, D, R, dt, dt,

@@ -33,7 +33,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     n_iter = len(data_loader)
     accum = args.accum_iter
     optimizer.zero_grad()
-    host_vals, copied = None, None
+    host_vals, copied, host_found = None, None, None
 
     for it, data in enumerate(log.log_every(data_loader, n_iter // 4, f"Epoch: [{epoch}]")):
         boundary_start = it % accum == 0
@@ -52,10 +52,21 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
             copied.record()
 
         loss_scaler(loss / accum, optimizer, parameters=model.parameters(), update_grad=boundary_end)
+        found_dev = getattr(loss_scaler, "_found", None)
+        if boundary_end and vals_dev.is_cuda and found_dev is not None:
+            # the step's found-inf word (2 = GEMM error word set, include/fvqa.h), read one iteration late: no wait here
+            if host_found is None:
+                host_found = torch.zeros(1, dtype=torch.float32, pin_memory=True)
+            host_found.copy_(found_dev, non_blocking=True)
 
         if vals_dev.is_cuda:
             copied.synchronize()                              # the forward has finished; the backward is queued
             vals = host_vals.tolist()
+            # the previous iteration's copy of found_inf has landed (same stream, queued before this forward); the word is
+            # sticky, so whichever iteration's value is seen, 2 means a step ran on a timed-out split-K exchange
+            if host_found is not None and float(host_found[0]) == 2.0:
+                raise RuntimeError("fvqa: a split-K exchange of the persistent GEMM timed out (found_inf = 2): that "
+                                   "optimizer step was skipped and the results of its launch are invalid")
         else:
             vals = vals_dev.tolist()
         loss_value = vals[0] + vals[1] + vals[2]
@@ -72,7 +83,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
 
     eng = getattr(getattr(model, "module", model), "_engine", None)
     if eng is not None:
-        eng.check_gemm_error()                                # one small read per epoch (include/fvqa.h: error word)
+        eng.check_gemm_error()                                # the last iteration's (include/fvqa.h: error word)
     log.synchronize_between_processes()
     print("Averaged stats:", log)
     return {k: m.global_avg for k, m in log.meters.items()}

@@ -11,8 +11,8 @@ import os
 from typing import Optional
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD = 0, 1, 3
-ABI_VERSION = 9
+EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST = 0, 1, 3, 6
+ABI_VERSION = 10
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -24,6 +24,7 @@ SIGNATURES = {
     "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
     "fvqa_gemm_sk_workspace": (_sz, []),
     "fvqa_gemm_nt_swiglu_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "fvqa_gemm_nt_swiglu_fwd_st": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "fvqa_gemm_nt_rider": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "fvqa_gemm_sk_describe": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i]),
     "fvqa_gemm_timing_enable": (_i, [_i]),
@@ -46,7 +47,7 @@ SIGNATURES = {
     "fvqa_qav_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "fvqa_qav_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "fvqa_grad_norm_workspace": (_sz, [_i]),
-    "fvqa_grad_unscale_norm": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "fvqa_grad_unscale_norm": (_i, [_p, _p, _i, _p, _f, _p, _p, _p, _p, _p, _sz, _p]),
     "fvqa_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p]),
     "fvqa_scaler_update": (_i, [_p, _p, _p, _p, _f, _f, _i, _p]),
     "fvqa_cast_rows": (_i, [_p, _p, _i, _i, _i, _p]),

@@ -32,6 +32,18 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/fvqa.h): tags measurements (profiles/*pmc*.json)
+    with the code they were taken on, independently of where or when the library was compiled."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files + [os.path.join(INCLUDE, "fvqa.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True

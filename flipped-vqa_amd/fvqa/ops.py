@@ -11,14 +11,10 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, F32
+from ._lib import BF16, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST, F32
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _DTN = {torch.float32: "f32", torch.bfloat16: "bf16"}
-
-# bench.py sets this to a list to collect (start_event, end_event, flops, kernel_key) per GEMM launch
-GEMM_TIMING = None
-
 
 def dt_code(dtype: torch.dtype) -> int:
     try:
@@ -62,26 +58,51 @@ def _need(cond: bool, msg: str):
 _GEMM_WS = {}
 
 
-def gemm_workspace(device, nbytes: int) -> torch.Tensor:
-    """One grow-only GEMM workspace per device (epoch flags + partial-tile slabs of the persistent kernel, reused by
-    every GEMM on the stream: launches are stream-ordered, so sharing is safe)."""
-    ws = _GEMM_WS.get(device)
-    if ws is None or ws.numel() < nbytes:
+def gemm_workspace(device=None, nbytes: int = 0) -> torch.Tensor:
+    """THE persistent-GEMM workspace of (device, current stream): epoch flags + partial-tile slabs, shared by every GEMM
+    launched on that stream (launches are stream-ordered, and include/fvqa.h allows one workspace per stream at a time:
+    a second stream gets a workspace of its own). Its size does not depend on the problem (fvqa_gemm_sk_workspace), so
+    the buffer — and the address of its error word — never moves once made."""
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        need = max(int(nbytes), int(_lib.load().fvqa_gemm_sk_workspace()))
         # zero-filled: the first 4 KiB are the epoch flags of the persistent GEMM (include/fvqa.h), which must
         # start at zero and are never reset afterwards
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _GEMM_WS[device] = ws
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        _GEMM_WS[key] = ws
+    if ws.numel() < nbytes:
+        raise RuntimeError("fvqa: GEMM workspace request exceeds fvqa_gemm_sk_workspace()")
     return ws
 
 
+def gemm_error_word(device=None) -> Optional[torch.Tensor]:
+    """8-byte view of the error word of the current stream's GEMM workspace (device memory; handed to
+    grad_unscale_norm so that a timed-out split-K exchange skips the optimizer step like an overflow); None while no
+    persistent GEMM has been launched on this stream."""
+    device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _GEMM_WS.get((idx, torch.cuda.current_stream(device).cuda_stream))
+    return None if ws is None else ws[:8]
+
+
 def gemm_error(ws: Optional[torch.Tensor] = None, device=None) -> int:
-    """The error word of a persistent-GEMM workspace (include/fvqa.h: non-zero after a launch whose split-K exchange
-    timed out). Default: the shared per-device workspace of this module. One device->host read."""
-    if ws is None:
-        ws = _GEMM_WS.get(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
-        if ws is None:
-            return 0
-    return int(ws[:8].view(torch.int64)[0].item())
+    """OR of the error words of the persistent-GEMM workspaces of `device` (include/fvqa.h: non-zero after a launch
+    whose split-K exchange timed out), or the word of the given workspace. Device->host reads: not for the step path."""
+    if ws is not None:
+        return int(ws[:8].view(torch.int64)[0].item())
+    idx = None
+    if device is not None:
+        device = torch.device(device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+    bad = 0
+    for (di, _), w in list(_GEMM_WS.items()):
+        if idx is None or di == idx:
+            bad |= int(w[:8].view(torch.int64)[0].item())
+    return bad
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
@@ -122,25 +143,18 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
     else:
         need = 0
     ws = gemm_workspace(a.device, need) if need else None
-    timing = GEMM_TIMING
-    if timing is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     ldc = out.stride(0) if out is not None else N
     _need(residual is None or residual.stride(0) == ldc, "gemm_nt: residual and out must share their row stride")
     rc = lib.fvqa_gemm_nt(_ptr(a), _ptr(b), _ptr(out), _ptr(residual), _ptr(tail), M, N, K, a.stride(0), b.stride(0),
                           ldc, m_split,
                           code, dt_code(out_dtype), epi, variant, _ptr(ws), ws.numel() if ws is not None else 0,
                           _stream())
-    if timing is not None:
-        e1.record()
-        key = f"{_DTN[a.dtype]}_{_DTN[out_dtype]}_{'res' if epi else 'none'}_{'fix' if need else 'plain'}"
-        timing.append((e0, e1, 2.0 * M * N * K, key))
     _lib.check(rc, "fvqa_gemm_nt")
     return out
 
 
-def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = False, residual=None, swiglu_ab=None):
+def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = False, residual=None, swiglu_ab=None,
+                  swiglu_st: bool = False):
     """out = a @ b^T (+ residual | SwiGLU' epilogue with swiglu_ab) and, on the CUs that launch leaves idle (or right
     after it), the small product rider_out (<= 16 rows) = rider_a @ rider_b^T (accumulate: fp32 rider_out += product).
     Operands may be column-block views of wider matrices (rows 16-byte aligned)."""
@@ -155,7 +169,7 @@ def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = 
     if swiglu_ab is not None:
         _need(tuple(out.shape) == (M, 2 * N) and swiglu_ab.shape == out.shape and out.is_contiguous() and
               swiglu_ab.is_contiguous(), "gemm_nt_rider: SwiGLU' operands")
-        epi, R = EPI_SWIGLU_BWD, swiglu_ab
+        epi, R = (EPI_SWIGLU_BWD_ST if swiglu_st else EPI_SWIGLU_BWD), swiglu_ab
     else:
         _need(tuple(out.shape) == (M, N), "gemm_nt_rider: out shape")
         if residual is not None:
@@ -174,24 +188,18 @@ def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = 
                       rider_b.stride(0), rider_out.stride(0), 1 if acc else 0)
     lib = _lib.load()
     ws = gemm_workspace(a.device, int(lib.fvqa_gemm_sk_workspace()))
-    timing = GEMM_TIMING
-    if timing is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     rc = lib.fvqa_gemm_nt_rider(_ptr(a), _ptr(b), _ptr(out), _ptr(R), M, N, K, a.stride(0), b.stride(0), ldc,
                                 dt_code(a.dtype), dt_code(out.dtype), epi, C.addressof(rd), _ptr(ws), ws.numel(),
                                 _stream())
-    if timing is not None:
-        e1.record()
-        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[a.dtype]}_{_DTN[out.dtype]}_rider"))
     _lib.check(rc, "fvqa_gemm_nt_rider")
     return out
 
 
-def gemm_timing_enable(on: bool) -> None:
-    """Measurement probe (include/fvqa.h fvqa_gemm_timing_enable): HIP events around every launch of
-    the 256x256 GEMM kernel on its launch stream, under whichever schedule is running."""
-    _lib.check(_lib.load().fvqa_gemm_timing_enable(1 if on else 0), "fvqa_gemm_timing_enable")
+def gemm_timing_enable(on, stride: int = 1) -> None:
+    """Measurement probe (include/fvqa.h fvqa_gemm_timing_enable): HIP events around every `stride`-th launch of
+    the persistent GEMM kernel on its launch stream, under whichever schedule is running; the other launches are
+    counted only (gemm_timing_read returns -2 us for them)."""
+    _lib.check(_lib.load().fvqa_gemm_timing_enable(int(stride) if on else 0), "fvqa_gemm_timing_enable")
 
 
 def gemm_timing_read():
@@ -206,8 +214,10 @@ def gemm_timing_read():
     return [(float(us[i]), float(fl[i]), int(kd[i])) for i in range(min(n, got))]
 
 
-def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: torch.Tensor):
-    """ab (M, 2*Hf) = x @ w13^T and z (M, Hf) = silu(a) * b in one launch; w13 / ab in the AB16 layout (pack_ab16)."""
+def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: torch.Tensor, st: bool = False):
+    """ab (M, 2*Hf) = x @ w13^T and z (M, Hf) = silu(a) * b in one launch; w13 / ab in the AB16 layout (pack_ab16).
+    st=True (the training step): `ab` receives the backward's factors s = silu(a), t = dz/da in the a and b slots
+    (FVQA_EPI_SWIGLU_FWD_ST), to be consumed by gemm_nt_swiglu_bwd(..., st=True)."""
     _dev(x, w13, ab, z)
     M, K = x.shape
     N = w13.shape[0]
@@ -216,15 +226,8 @@ def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: 
           "gemm_nt_swiglu_fwd: ab / z shape")
     lib = _lib.load()
     ws = gemm_workspace(x.device, int(lib.fvqa_gemm_sk_workspace()))
-    timing = GEMM_TIMING
-    if timing is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    rc = lib.fvqa_gemm_nt_swiglu_fwd(_ptr(x), _ptr(w13), _ptr(ab), _ptr(z), M, N // 2, K, K, K, dt_code(x.dtype),
-                                     _ptr(ws), ws.numel(), _stream())
-    if timing is not None:
-        e1.record()
-        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[x.dtype]}_{_DTN[x.dtype]}_swiglu_fwd"))
+    fn = lib.fvqa_gemm_nt_swiglu_fwd_st if st else lib.fvqa_gemm_nt_swiglu_fwd
+    rc = fn(_ptr(x), _ptr(w13), _ptr(ab), _ptr(z), M, N // 2, K, K, K, dt_code(x.dtype), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "fvqa_gemm_nt_swiglu_fwd")
     return z
 
@@ -246,9 +249,10 @@ def unpack_ab16(ab: torch.Tensor):
     return v[..., 0, :].reshape(*lead, H2 // 2), v[..., 1, :].reshape(*lead, H2 // 2)
 
 
-def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, dab: torch.Tensor):
+def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, dab: torch.Tensor, st: bool = False):
     """dab (M, 2*Hf) = d/d(a,b)[silu(a)*b] with dz = g (M,D) @ w2_t (Hf,D)^T formed in the GEMM
-    accumulators (the SwiGLU backward is the GEMM's epilogue; dz never reaches HBM). ab / dab: AB16 layout."""
+    accumulators (the SwiGLU backward is the GEMM's epilogue; dz never reaches HBM). ab / dab: AB16 layout.
+    st=True: `ab` holds (s, t) as left by gemm_nt_swiglu_fwd(..., st=True)."""
     _dev(g, w2_t, ab, dab)
     M, K = g.shape
     N = w2_t.shape[0]
@@ -258,16 +262,10 @@ def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, da
     lib = _lib.load()
     need = int(lib.fvqa_gemm_sk_workspace())                 # this epilogue lives in the persistent kernel
     ws = gemm_workspace(g.device, need)
-    timing = GEMM_TIMING
-    if timing is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     rc = lib.fvqa_gemm_nt(_ptr(g), _ptr(w2_t), _ptr(dab), _ptr(ab), None, M, N, K, K, K, 2 * N, M, dt_code(g.dtype),
-                          dt_code(g.dtype), EPI_SWIGLU_BWD, 0, _ptr(ws), ws.numel() if ws is not None else 0,
+                          dt_code(g.dtype), EPI_SWIGLU_BWD_ST if st else EPI_SWIGLU_BWD, 0, _ptr(ws),
+                          ws.numel() if ws is not None else 0,
                           _stream())
-    if timing is not None:
-        e1.record()
-        timing.append((e0, e1, 2.0 * M * N * K, f"{_DTN[g.dtype]}_{_DTN[g.dtype]}_swiglu_plain"))
     _lib.check(rc, "fvqa_gemm_nt(swiglu_bwd)")
     return dab
 
@@ -522,14 +520,20 @@ def grad_norm_workspace(n_seg: int) -> int:
     return int(_lib.load().fvqa_grad_norm_workspace(n_seg))
 
 
-def grad_unscale_norm(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace):
-    _dev(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace)
+def grad_unscale_norm(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace, grad_div: float = 1.0,
+                      gemm_err: Optional[torch.Tensor] = None):
+    """grad_div: replicas summed into `grad` (the data-parallel mean is applied here); gemm_err: the 8-byte error word of
+    the GEMM workspace (gemm_error_word) — non-zero makes found_inf 2 and the optimizer step a no-op."""
+    _dev(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace, gemm_err)
+    _need(grad_div >= 1.0, "grad_unscale_norm: grad_div")
+    _need(gemm_err is None or gemm_err.numel() * gemm_err.element_size() >= 8, "grad_unscale_norm: gemm_err")
     n_seg = seg_off.numel() - 1
     _need(grad.dtype == torch.float32 and seg_off.dtype == torch.int64 and n_seg >= 1, "grad_unscale_norm: types")
     _need(seg_sq.numel() >= n_seg and seg_sq.dtype == torch.float32, "grad_unscale_norm: seg_sq")
     wbytes = workspace.numel() * workspace.element_size()
-    rc = _lib.load().fvqa_grad_unscale_norm(_ptr(grad), _ptr(seg_off), n_seg, _ptr(scale), _ptr(seg_sq),
-                                            _ptr(found_inf), _ptr(total_norm), _ptr(workspace), wbytes, _stream())
+    rc = _lib.load().fvqa_grad_unscale_norm(_ptr(grad), _ptr(seg_off), n_seg, _ptr(scale), float(grad_div),
+                                            _ptr(gemm_err), _ptr(seg_sq), _ptr(found_inf), _ptr(total_norm),
+                                            _ptr(workspace), wbytes, _stream())
     _lib.check(rc, "fvqa_grad_unscale_norm")
 
 

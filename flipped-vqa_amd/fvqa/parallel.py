@@ -6,8 +6,22 @@ reducer all-reduces the same ~4.5 M scalars on every backward.
 The averaging rule is backend-agnostic (tests drive it with gloo on CPU tensors)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def allreduce_sum_(flat_grad: torch.Tensor, group=None) -> int:
+    """In-place SUM over ranks of one flat gradient buffer; returns the number of replicas summed (the divisor of the
+    mean, which the fused unscale kernel applies together with 1/loss-scale: no pass of its own)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    # (FVQA_DP_FORCE_ALLREDUCE=1: tests run the collective on a one-rank group too — RCCL beside libfvqa_hip.so)
+    if world > 1 or os.environ.get("FVQA_DP_FORCE_ALLREDUCE") == "1":
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return world
 
 
 def allreduce_mean_(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
@@ -50,6 +64,7 @@ class DataParallel(torch.nn.Module):
         super().__init__()
         self.module = module
         self.group = group
+        self.comm_events = None
         self.broadcast_params()
 
     def forward(self, *a, **k):
@@ -73,6 +88,17 @@ class DataParallel(torch.nn.Module):
             self._bcast(loss_scaler._scale)
             self._bcast(loss_scaler._tracker)
 
-    def sync_grads(self):
+    def sync_grads(self) -> int:
+        """ONE all-reduce(SUM) of the flat gradient buffer over RCCL/xGMI; returns the replica count, by which the
+        loss scaler's unscale kernel divides (fvqa_grad_unscale_norm grad_div). With `comm_events` set to a list,
+        each call appends a (start, end) event pair recorded on the current stream (bench.py: allreduce_ms)."""
         flat = self.module.flat_params()
-        allreduce_mean_(flat.flat_grad, self.group)
+        ev = self.comm_events
+        if ev is not None and flat.flat_grad.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            n = allreduce_sum_(flat.flat_grad, self.group)
+            e1.record()
+            ev.append((e0, e1))
+            return n
+        return allreduce_sum_(flat.flat_grad, self.group)

@@ -87,7 +87,7 @@ class Arena:
         self.lse_a = e(L, n_seq * H * S, dtype=f32)
         self.lse_t = e(L, n_seq * H * S, dtype=f32)
         self.h = e(L, R, D)
-        self.ab = e(L, R, 2 * Hf)
+        self.ab = e(L, R, 2 * Hf)                # AB16 slots; the step keeps (s, t) = (silu(a), dz/da) there, not (a, b)
         self.xn = e(R, D)
         self.adapter_c = e(L, A, D)             # storage-dtype cast of the walked layers' adapter prompts
         self.hn = e(R, D)
@@ -159,7 +159,7 @@ class StepEngine:
     def layer_plan(self, ar: "Arena", grads: "FlatParams", vstart: torch.Tensor):
         """fvqa_layer_plan for this arena (built once, cached on the arena; csrc/schedule.hip walks it)."""
         key = (vstart.data_ptr(), grads.flat_grad.data_ptr())
-        if getattr(ar, "_plan_key", None) == key:
+        if getattr(ar, "_plan_key", (None,))[:2] == key and ar._plan_key[2] == ops.gemm_workspace(self.device).data_ptr():
             return ar._plan
         m, pk, L = self.model, self.pack, self.L
         plan = _lib.LayerPlan()
@@ -192,17 +192,19 @@ class StepEngine:
         plan.attn_ws_bytes = ar.attn_ws.numel()
         lib = _lib.load()
         need = int(lib.fvqa_layers_gemm_workspace(C.addressof(plan)))
-        if getattr(ar, "plan_ws", None) is None or ar.plan_ws.numel() < need:
-            # zero-filled: the first 4 KiB are the persistent GEMM's epoch flags (include/fvqa.h)
-            ar.plan_ws = torch.zeros(max(need, 4096), dtype=torch.uint8, device=self.device)
-        plan.gemm_ws, plan.gemm_ws_bytes = ar.plan_ws.data_ptr(), ar.plan_ws.numel()
-        ar._plan, ar._plan_keep, ar._plan_key = plan, keep, key
+        # the stream's one GEMM workspace (ops.gemm_workspace): every launch of the step, from either schedule, shares
+        # its flags, slabs and ERROR word, which the loss scaler hands to the unscale kernel
+        ws = ops.gemm_workspace(self.device, need)
+        key = key + (ws.data_ptr(),)
+        plan.gemm_ws, plan.gemm_ws_bytes = ws.data_ptr(), ws.numel()
+        ar._plan, ar._plan_keep, ar._plan_key = plan, keep + [ws], key
         return plan
 
     @staticmethod
     def use_native_schedule() -> bool:
-        # the per-kernel Python schedule stays for per-launch timing (bench.py) and debugging
-        return os.environ.get("FVQA_PY_SCHEDULE") != "1" and ops.GEMM_TIMING is None
+        # the per-kernel Python schedule stays for debugging (bench.py's launch probe lives in the library and works
+        # under either schedule)
+        return os.environ.get("FVQA_PY_SCHEDULE") != "1"
 
     # ------------------------------------------------------------------ helpers
     def arena(self, n_seq, S) -> Arena:
@@ -226,10 +228,6 @@ class StepEngine:
         """Raise if any persistent-GEMM launch of this engine reported a timed-out split-K exchange (the error word of
         its workspaces, include/fvqa.h). One small device->host read per workspace: call it at an epoch boundary."""
         bad = ops.gemm_error(device=self.device)
-        for ar in list(self._arena.values()) + list(self._gen_arena.values()):
-            ws = getattr(ar, "plan_ws", None)
-            if ws is not None:
-                bad |= ops.gemm_error(ws)
         if bad:
             raise RuntimeError("fvqa: a split-K exchange of the persistent GEMM timed out (workspace error word "
                                f"{bad}); the results of that step are invalid")
@@ -323,7 +321,7 @@ class StepEngine:
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
             ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)           # h = x + o·Wo^T
             ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
-            ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z)     # ab = hn·(W1|W3)^T, z = silu(a)*b
+            ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z, st=True)   # z = silu(a)*b; ab[i] <- (s, t)
             ops.gemm_nt(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i])   # x' = h + z·W2^T
             if i + 1 < L:
                 ops.rmsnorm_fwd(ar.xs[i + 1], pk.an[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, rows=R)
@@ -384,10 +382,10 @@ class StepEngine:
         g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
         for i in reversed(range(L)):
             if i + 1 < L:                    # dz·SwiGLU' in the epilogue; rider: the previous layer's adapter-grad rows
-                ops.gemm_nt_rider(cur, pk.w2_t[i], ar.dab, swiglu_ab=ar.ab[i], rider_a=ar.dqkv[R:, D:],
+                ops.gemm_nt_rider(cur, pk.w2_t[i], ar.dab, swiglu_ab=ar.ab[i], swiglu_st=True, rider_a=ar.dqkv[R:, D:],
                                   rider_b=pk.wqkv_t[i + 1][:, D:], rider_out=g_adapter[i + 1], accumulate=True)
             else:
-                ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab)
+                ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab, st=True)
             ops.gemm_nt(ar.dab, pk.w13_t[i], t)
             ops.rmsnorm_bwd(t, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
             ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)

@@ -237,14 +237,17 @@ class NativeScalerWithGradNormCount:
         if not update_grad:
             return None
         flat = optimizer.flat
+        div = 1
         if optimizer.grad_sync is not None:
-            optimizer.grad_sync()
+            r = optimizer.grad_sync()            # all-reduce(SUM) -> replica count; the mean's 1/world rides in the unscale kernel
+            div = r if isinstance(r, int) and r > 1 else 1
         n_seg = flat.seg_off.numel() - 1
         if getattr(self, "_ws", None) is None or self._seg_sq.numel() < n_seg:
             self._seg_sq = torch.empty(n_seg, dtype=torch.float32, device=self._dev)
             self._ws = torch.empty(ops.grad_norm_workspace(n_seg), dtype=torch.uint8, device=self._dev)
+        # a timed-out split-K exchange (error word of the stream's GEMM workspace) makes found_inf 2: skipped like an overflow
         ops.grad_unscale_norm(flat.flat_grad, flat.seg_off, self._scale, self._seg_sq, self._found, self._norm,
-                              self._ws)
+                              self._ws, grad_div=float(div), gemm_err=ops.gemm_error_word(self._dev))
         if clip_grad is not None:
             flat.flat_grad.mul_(torch.clamp(clip_grad / (self._norm + 1e-6), max=1.0))
         optimizer.step(found_inf=self._found)

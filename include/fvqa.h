@@ -42,6 +42,10 @@ extern "C" {
 #define FVQA_EPI_SWIGLU_BWD 3 /* acc = dz (M,N): R = ab (M,2N), C = dab (M,2N) <- d/d(a,b) of silu(a)*b
                                 (llama/model.py:142 backward), both in the AB16 layout below; ldc must be 2N */
 #define FVQA_EPI_SWIGLU_FWD 4 /* fvqa_gemm_nt_swiglu_fwd only: C = ab (M,N) AND z = silu(a)*b (M,N/2) */
+#define FVQA_EPI_SWIGLU_FWD_ST 5 /* fvqa_gemm_nt_swiglu_fwd_st only: as 4, but C receives, in the a and b slots of the AB16
+                                   layout, s = silu(a) = dz/db and t = b*sigma(a)*(1 + a*(1 - sigma(a))) = dz/da: what
+                                   the backward of llama/model.py:142 multiplies by */
+#define FVQA_EPI_SWIGLU_BWD_ST 6 /* as 3 with R = that (s, t) buffer: C = dab = (acc * t, acc * s) */
 /* AB16: the layout of every (rows, 2*hidden) buffer that holds the W1 and W3 projections (or their gradients) side by
  * side: column 32k + c is a[16k + c], column 32k + 16 + c is b[16k + c] (c < 16), i.e. the rows of W1 and W3 are
  * interleaved in blocks of 16 in the packed W1|W3 matrix. One MFMA wave of the W1|W3 GEMM then holds a and b of the
@@ -72,6 +76,12 @@ int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R, float* ta
  * interleaved in blocks of 16 (AB16). Needs the fvqa_gemm_sk_workspace() workspace. */
 int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K, int lda,
                             int ldb, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* The training step's form: same product and the same z, but `st` (M, 2*hidden, AB16) receives the two factors of the
+ * SwiGLU backward (FVQA_EPI_SWIGLU_FWD_ST) instead of a and b — nothing else on the training path reads a or b, and the
+ * dH·W2^T GEMM's epilogue (FVQA_EPI_SWIGLU_BWD_ST) then is two multiplies per element instead of an exponential, a
+ * reciprocal and a dozen operations (llama/model.py:142 and its autograd). */
+int fvqa_gemm_nt_swiglu_fwd_st(const void* A, const void* B13, void* st, void* z, int M, int hidden, int K, int lda,
+                               int ldb, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* fvqa_gemm_workspace: bytes of `workspace` the kernel variant 0 picks for the problem needs (0: none).
  * Its FIRST 4096 BYTES are the epoch flags of the persistent kernel (csrc/gemm_sk.hip): the caller zeroes them ONCE
  * after allocating the buffer (256-byte aligned); no call ever needs them reset. One workspace serves one stream at
@@ -109,13 +119,16 @@ int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const void* R, int
                        void* workspace, size_t workspace_bytes, void* stream);
 int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
                           int32_t* segs_out, int max_segs);
-/* Measurement probe (bench.py roofline; no reference counterpart): while enabled, every launch of the
- * 256x256 GEMM kernel is bracketed by HIP events on ITS launch stream (the kernel only — fix-up
- * passes are outside the pair). fvqa_gemm_timing_read synchronises, returns the number of launches
- * recorded since enable and fills up to `max` entries: duration (us), algorithmic FLOPs (2*M*N*K of
- * that launch) and kind = epilogue | split_k << 4 | out_is_f32 << 5 | in_is_f32 << 6; it then clears
- * the record (max <= 0: size query only, nothing cleared). enable(0) stops recording and frees the probe. Launches from
- * any host thread are recorded (the step's backward runs on the autograd thread); switch it while no launch is in flight. */
+/* Measurement probe (bench.py roofline; no reference counterpart): while enabled, launches of the persistent
+ * 256x256 GEMM kernel are bracketed by HIP events on THEIR launch stream. enable(n): n = 1 brackets every launch, n > 1
+ * every n-th launch (the others are only counted) — an event pair idles the chip for ~5 us, and a stream with one after
+ * each of its 258 launches per step runs at a lighter duty cycle (on a power-limited chip: a higher clock) than the
+ * un-instrumented step; a co-prime stride samples every launch position over a few steps at 1/n of that disturbance.
+ * fvqa_gemm_timing_read synchronises, returns the number of launches recorded since enable and fills up to `max`
+ * entries: duration (us; -2 = counted but not bracketed, -1 = event error), algorithmic FLOPs (2*M*N*K of that launch)
+ * and kind = epilogue | split_k << 4 | out_is_f32 << 5 | in_is_f32 << 6; it then clears the record (max <= 0: size query
+ * only, nothing cleared). enable(0) stops recording and frees the probe. Launches from any host thread are recorded (the
+ * step's backward runs on the autograd thread); switch it while no launch is in flight. */
 int fvqa_gemm_timing_enable(int on);
 int fvqa_gemm_timing_read(int max, float* us, double* flops, int* kind);
 
@@ -223,13 +236,17 @@ int fvqa_qav_head_bwd(const void* xn, const float* vf_raw, const int64_t* labels
  * One flat fp32 buffer holds every trainable gradient; seg_off (n_seg+1) int64 marks the
  * per-parameter segments. scale, found_inf, step, growth_tracker are DEVICE fp32 scalars, so
  * the optimizer step needs no device->host read.
- * fvqa_grad_unscale_norm: g *= 1/scale[0] in place; seg_sq[i] = sum g^2 over segment i;
+ * fvqa_grad_unscale_norm: g *= 1/(scale[0]*grad_div) in place; seg_sq[i] = sum g^2 over segment i;
  * total_norm[0] = sqrt(sum_i seg_sq[i]) (the norm of per-parameter norms, util/misc.py:292);
- * found_inf[0] = 1 if any gradient is non-finite else 0 (GradScaler.unscale_). */
+ * found_inf[0] = 1 if any gradient is non-finite else 0 (GradScaler.unscale_).
+ * grad_div >= 1: the number of data-parallel replicas whose gradients were SUMMED into `grad` by the all-reduce (DDP's
+ * mean of train.py:115-117 without a pass of its own; 1 on a single GPU).
+ * gemm_err (may be NULL): device address of a persistent-GEMM workspace's error word (fvqa_gemm_workspace); when it is
+ * non-zero the step is skipped like an overflow and found_inf[0] = 2. */
 size_t fvqa_grad_norm_workspace(int n_seg);
-int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n_seg, const float* scale,
-                           float* seg_sq, float* found_inf, float* total_norm, void* workspace,
-                           size_t workspace_bytes, void* stream);
+int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n_seg, const float* scale, float grad_div,
+                           const void* gemm_err, float* seg_sq, float* found_inf, float* total_norm,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* AdamW (decoupled weight decay, bias correction with t = step[0]+1), skipped entirely when
  * found_inf[0] != 0 (GradScaler.step semantics). found_inf may be NULL. */
 int fvqa_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

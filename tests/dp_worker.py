@@ -27,7 +27,56 @@ def perturb_trainables(model, seed):
     flat.add_(0.01 * torch.randn(flat.numel(), generator=g).to(flat.device))
 
 
+def rccl_one_rank(port, out_dir):
+    """RCCL beside libfvqa_hip.so on one GPU: a ONE-rank `nccl` process group (nccl == RCCL on ROCm), train.py's wiring
+    (DataParallel broadcast + all-reduce of the real flat gradient buffer of a 7B-width model, forced although world
+    is 1, + loss scaler + FusedAdamW) for 3 steps on the HIP step — bitwise equal to the same steps without any process
+    group. Reference: train.py:104-117, util/misc.py:220-250."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, FVQA_DP_FORCE_ALLREDUCE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    import util.misc as misc
+    from fvqa import synth
+    from fvqa.optim import FusedAdamW, param_groups_weight_decay
+    from fvqa.parallel import DataParallel
+    from tests.gpu_util import build_model
+
+    cfg = synth.preset("7b_l2", batch_size=2)
+
+    def run(dp):
+        model, args = build_model(cfg, torch.bfloat16)
+        flat = model.flat_params()
+        opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=0.01, betas=(0.9, 0.95), flat=flat)
+        net = model
+        if dp:
+            net = DataParallel(model)                           # broadcast over RCCL
+            net.comm_events = []
+            opt.grad_sync = net.sync_grads
+        scaler = misc.NativeScalerWithGradNormCount()
+        out = []
+        for i in range(3):
+            opt.zero_grad()
+            a, b, c = net(synth.make_batch(cfg, seed=200 + i))
+            scaler(a + b + c, opt, parameters=None, update_grad=True)
+            torch.cuda.synchronize()
+            out.append(flat.flat.detach().cpu().clone())
+        model._engine.check_gemm_error()
+        ms = [e0.elapsed_time(e1) for e0, e1 in net.comm_events] if dp else []
+        return out, flat.flat_grad.numel() * 4, ms
+
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    backend, ranks = dist.get_backend(), dist.get_world_size()
+    with_dp, nbytes, ms = run(True)
+    dist.barrier()
+    dist.destroy_process_group()
+    plain, _, _ = run(False)
+    torch.save(dict(with_dp=with_dp, plain=plain, backend=backend, ranks=ranks, allreduce_bytes=nbytes, allreduce_ms=ms),
+               os.path.join(out_dir, "rccl1.pt"))
+
+
 def main():
+    if len(sys.argv) > 5 and sys.argv[5] == "rccl1":
+        return rccl_one_rank(sys.argv[3], sys.argv[4])
     rank, world, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,7 +101,7 @@ def main():
     def sync():
         if step_no["i"] == INF_STEP and rank == INF_RANK:       # an overflow on ONE rank
             flat.flat_grad[7] = float("inf")
-        net.sync_grads()
+        return net.sync_grads()
 
     opt.grad_sync = sync
     for i in range(N_STEPS):
@@ -65,6 +114,7 @@ def main():
         trace[f"scale{i}"] = float(scaler._scale.item())
         trace[f"found{i}"] = float(scaler._found.item())
         trace[f"step{i}"] = float(opt.step_dev.item())
+    model._engine.check_gemm_error()                            # (two persistent grids share this GPU: no exchange timed out)
     torch.save(trace, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

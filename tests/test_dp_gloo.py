@@ -93,10 +93,10 @@ def _dp_worker(rank, world, port, out_dir):
     m = _Module(rank)
     g_local = m.flat_params().flat_grad.clone()
     net = DataParallel(m)                           # constructor broadcasts rank 0's parameters (as torch DDP does)
-    net.sync_grads()
+    n_rep = net.sync_grads()                        # all-reduce(SUM); returns the divisor the unscale kernel applies
     opt = _Opt(rank)
     net.broadcast_optimizer(opt)
-    torch.save(dict(flat=m.flat_params().flat, grad=m.flat_params().flat_grad, g_local=g_local, m=opt.exp_avg,
+    torch.save(dict(flat=m.flat_params().flat, grad=m.flat_params().flat_grad, g_local=g_local, n_rep=n_rep, m=opt.exp_avg,
                     v=opt.exp_avg_sq, step=opt.step_dev), os.path.join(out_dir, f"dp{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -110,7 +110,10 @@ def test_dataparallel_broadcasts_rank0_state_and_averages_grads(tmp_path):
     r0, r1 = torch.load(tmp_path / "dp0.pt"), torch.load(tmp_path / "dp1.pt")
     assert torch.equal(r0["flat"], _Flat(0).flat) and torch.equal(r1["flat"], r0["flat"])
     assert not torch.equal(_Flat(1).flat, _Flat(0).flat)
-    want = (r0["g_local"] + r1["g_local"]) / world
+    # sync_grads leaves the SUM and hands back the replica count (fvqa_grad_unscale_norm's grad_div: the mean rides in
+    # the unscale kernel's factor 1/(scale*world) — exact for the power-of-two world sizes of one node)
+    want = r0["g_local"] + r1["g_local"]
+    assert r0["n_rep"] == world and r1["n_rep"] == world
     assert torch.equal(r0["grad"], want) and torch.equal(r1["grad"], want)
     for k, v in (("m", 0.0), ("v", 0.0), ("step", 3.0)):
         assert torch.all(r0[k] == v) and torch.all(r1[k] == v)

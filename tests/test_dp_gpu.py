@@ -76,10 +76,27 @@ def test_two_ranks_stay_bitwise_equal_and_match_single_process_average(tmp_path)
             g1[7] = float("inf")
         opt.zero_grad()
         a, b, c = model(synth.make_batch(cfg, seed=W.batch_seed(0, world, i)))
-        opt.grad_sync = lambda: flat.flat_grad.add_(g1).div_(world)
+        opt.grad_sync = lambda: (flat.flat_grad.add_(g1), world)[1]      # SUM + replica count, as DataParallel.sync_grads
         scaler(a + b + c, opt, parameters=None, update_grad=True)
         torch.cuda.synchronize()
         assert torch.equal(flat.flat.cpu(), t0[f"p{i}"]), f"2-rank result != single-process average at step {i}"
+
+
+def test_one_rank_rccl_group_runs_beside_the_hip_library(tmp_path):
+    """The collective backend of the N>1 path on this one-GPU box: a child process creates a 1-rank `nccl` (RCCL) group,
+    broadcasts and all-reduces the real flat gradient buffer (7B width: ~13 MB) inside train.py's wiring around the HIP
+    step; parameters after each of 3 steps are bitwise those of the same steps with no process group."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), "0", "1", str(_free_port()),
+                        str(tmp_path), "rccl1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    t = torch.load(tmp_path / "rccl1.pt")
+    assert t["backend"] == "nccl" and t["ranks"] == 1
+    assert t["allreduce_bytes"] > 12 * 2 ** 20 and len(t["allreduce_ms"]) == 3 and all(m > 0 for m in t["allreduce_ms"])
+    for i, (a, b) in enumerate(zip(t["with_dp"], t["plain"])):
+        assert torch.equal(a, b), f"RCCL path changed the result at step {i}"
+    assert not torch.equal(t["plain"][0], t["plain"][2])
+    print(f"RCCL 1-rank all-reduce of {t['allreduce_bytes'] / 2**20:.1f} MiB: {t['allreduce_ms']} ms")
 
 
 def test_bench_self_launches_two_ranks_from_a_plain_shell(tmp_path):

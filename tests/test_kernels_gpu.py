@@ -174,6 +174,43 @@ def test_gemm_nt_swiglu_fwd_epilogue(dtype, M, Hf, D):
     assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Hf,D", [(74, 768, 256), (1024, 1536, 512), (1024, 11008, 1024), (3072, 2816, 512),
+                                    (1024, 144, 4096)])
+def test_gemm_nt_swiglu_st_pair(dtype, M, Hf, D):
+    """The training step's pair (FVQA_EPI_SWIGLU_FWD_ST / _BWD_ST): the forward leaves, in the a and b slots of `ab`,
+    s = silu(a) and t = b sigma(a)(1 + a(1 - sigma(a))) — the two factors of the backward of llama/model.py:142 — and
+    the same z; the dH·W2^T GEMM's epilogue then forms d(a|b) = (dz t, dz s). Against fp64: s, t, z, and the gradients
+    the pair produces against the oracle's swiglu_bwd on the exact a, b."""
+    if dtype == torch.float32 and M * Hf * D > 2 ** 32:
+        pytest.skip("fp32 covered by the smaller shapes")
+    x = rnd(M, D, dtype=dtype, seed=45)
+    w1, w3 = rnd(Hf, D, dtype=dtype, scale=2 / math.sqrt(D), seed=46), rnd(Hf, D, dtype=dtype, scale=2 / math.sqrt(D), seed=47)
+    w13 = ops.pack_ab16(w1.T.contiguous(), w3.T.contiguous()).T.contiguous()
+    st = torch.empty(M, 2 * Hf, dtype=dtype, device=DEV)
+    z = torch.empty(M, Hf, dtype=dtype, device=DEV)
+    ops.gemm_nt_swiglu_fwd(dev(x), dev(w13), st, z, st=True)
+    a, b = x.double() @ w1.double().T, x.double() @ w3.double().T
+    sg = torch.sigmoid(a)
+    s_ref, t_ref = a * sg, b * sg * (1 + a * (1 - sg))
+    gs, gt = ops.unpack_ab16(st)
+    assert rel(gs, s_ref) < tol(dtype, 5e-5, 1e-2) and rel(gt, t_ref) < tol(dtype, 5e-5, 1e-2)
+    assert rel(z, s_ref * b) < tol(dtype, 5e-5, 2e-2)
+    # z equals what the (a, b)-storing epilogue writes, up to one rounding of s (fast reciprocal vs division)
+    ab, z0 = torch.empty_like(st), torch.empty_like(z)
+    ops.gemm_nt_swiglu_fwd(dev(x), dev(w13), ab, z0)
+    assert rel(z, z0.double()) < tol(dtype, 1e-6, 8e-3)
+    # backward through the saved factors
+    g, w2t = rnd(M, D, dtype=dtype, seed=41), rnd(Hf, D, dtype=dtype, scale=1 / math.sqrt(D), seed=42)
+    dab = torch.empty(M, 2 * Hf, dtype=dtype, device=DEV)
+    ops.gemm_nt_swiglu_bwd(dev(g), dev(w2t), st, dab, st=True)
+    dz = g.double() @ w2t.double().T
+    da, db = ref_cpu.swiglu_bwd(dz, a, b)
+    ga, gb = ops.unpack_ab16(dab)
+    assert rel(ga, da) < tol(dtype, 5e-5, 1.5e-2)
+    assert rel(gb, db) < tol(dtype, 5e-5, 1.5e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (1, 520, 256), (16, 1000, 2816), (3, 22016, 1024)])
 def test_gemm_nt_skinny_decode_shape(M, N, K):
     """M <= 16 (one new token per sequence, generation path): the weight-streaming kernel, forced (variant 12)
@@ -599,6 +636,24 @@ def test_grad_norm_and_adamw_match_torch():
     ops.adamw_step(flat, grad2, m, v, 0.05, 0.9, 0.95, 1e-8, 0.14, step, found)
     ops.scaler_update(step, sc, tracker, found, 2.0, 0.5, 2)
     assert torch.equal(flat, before) and step.item() == 3.0 and sc.item() == scale
+    # data-parallel divisor: gradients SUMMED over 4 replicas come out as their mean (exact: power-of-two factors)
+    grad3 = dev(g0 * scale * 4)
+    sc3 = torch.tensor([scale], device=DEV)
+    ops.grad_unscale_norm(grad3, seg, sc3, seg_sq, found, norm, ws, grad_div=4.0)
+    assert found.item() == 0.0 and torch.equal(grad3, grad)
+    # a set GEMM error word: found_inf = 2, the step is a no-op, the scale backs off
+    err = torch.zeros(8, dtype=torch.uint8, device=DEV)
+    grad4 = dev(g0 * scale)
+    ops.grad_unscale_norm(grad4, seg, sc3, seg_sq, found, norm, ws, gemm_err=err)
+    assert found.item() == 0.0
+    err.view(torch.int64)[0] = 1
+    grad4 = dev(g0 * scale)
+    ops.grad_unscale_norm(grad4, seg, sc3, seg_sq, found, norm, ws, gemm_err=err)
+    assert found.item() == 2.0
+    before = flat.clone()
+    ops.adamw_step(flat, grad4, m, v, 0.05, 0.9, 0.95, 1e-8, 0.14, step, found)
+    ops.scaler_update(step, sc3, tracker, found, 2.0, 0.5, 2)
+    assert torch.equal(flat, before) and step.item() == 3.0 and sc3.item() == scale * 0.5
 
 
 def test_gemm_error_word_is_read_back_and_reported():
@@ -613,3 +668,44 @@ def test_gemm_error_word_is_read_back_and_reported():
     assert ops.gemm_error(ws) == 0
     ws[:8].view(torch.int64)[0] = 1
     assert ops.gemm_error(ws) == 1
+
+
+def test_set_error_word_skips_the_optimizer_step_and_raises():
+    """A timed-out split-K exchange must not train on garbage: with the error word of the stream's GEMM workspace set,
+    the loss scaler's step is a no-op (found_inf = 2, read on the device: no extra host read on the step's path) and the
+    engine's check raises. Reference: the GradScaler skip of util/misc.py:259-273."""
+    import util.misc as misc
+    from fvqa import synth
+    from fvqa.optim import FusedAdamW, param_groups_weight_decay
+    from tests.gpu_util import build_model
+    cfg = synth.preset("7b_l2", batch_size=2)
+    model, args = build_model(cfg, torch.bfloat16)
+    flat = model.flat_params()
+    opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=0.01, betas=(0.9, 0.95), flat=flat)
+    scaler = misc.NativeScalerWithGradNormCount()
+    batch = synth.make_batch(cfg, seed=3)
+
+    def step():
+        opt.zero_grad()
+        a, b, c = model(batch)
+        scaler(a + b + c, opt, parameters=None, update_grad=True)
+        torch.cuda.synchronize()
+
+    p0 = flat.flat.clone()
+    step()
+    assert scaler._found.item() == 0.0 and not torch.equal(flat.flat, p0)
+    model._engine.check_gemm_error()
+    word = ops.gemm_error_word(flat.flat.device)
+    assert word is not None                                  # 7B-width projections run on the persistent kernel
+    p1, s1 = flat.flat.clone(), scaler._scale.item()
+    word.view(torch.int64)[0] = 4
+    try:
+        step()
+        assert scaler._found.item() == 2.0
+        assert torch.equal(flat.flat, p1) and scaler._scale.item() == 0.5 * s1
+        with pytest.raises(RuntimeError, match="split-K exchange"):
+            model._engine.check_gemm_error()
+    finally:
+        word.view(torch.int64)[0] = 0
+    step()
+    assert scaler._found.item() == 0.0 and not torch.equal(flat.flat, p1)

@@ -71,8 +71,9 @@ def main():
         res[k] = e
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(ROOT, "flipped-vqa_amd"))
-    from fvqa import _lib                                   # host-only call: the ABI version the passes ran against
-    doc = {"fvqa_version": int(_lib.load().fvqa_version()),
+    from fvqa import _lib, build                            # host-only calls: ABI version + hash of the kernel sources
+    # run this in the SAME gpurun call as the counter passes: the tag is the code the counters were collected on
+    doc = {"fvqa_version": int(_lib.load().fvqa_version()), "source_hash": build.source_hash(),
            "command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 2 --warmup 1 "
                       "--no_cpu_baseline (C2: LLaMA-7B bf16 B=8 S=128 VQA)",
            "kernels": res}

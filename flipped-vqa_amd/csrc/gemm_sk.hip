@@ -31,6 +31,11 @@ using namespace fvqa_ring;
 
 typedef unsigned long long u64;
 constexpr int SLAB_FLOATS = 8 * 32 * 256;            // 8 waves x 32 blocks x (64 lanes x 4) = 256 KiB
+#ifdef FVQA_SK_NOPACK
+constexpr bool SK_PACK24 = false;                       // tuning build: fp32 slabs everywhere (the round-2 exchange)
+#else
+constexpr bool SK_PACK24 = true;
+#endif
 constexpr size_t SYNC_BYTES = 4096;                   // u64 words: [0] error, [1 + workgroup] epoch flags (<= 511)
 
 // A second, independent product of at most 16 rows (bf16) that rides on the CUs the main problem leaves idle:
@@ -292,20 +297,54 @@ __device__ __forceinline__ void store_swiglu(f32x4 (&acc)[8][4], char* smem, con
   }
 }
 
-template <int NP>
+// 24-bit slab format (PACK: launches whose tile is stored as bf16). A partial sum crosses the fabric with sign, the full
+// 8-bit exponent and the top 15 mantissa bits (round to nearest on the dropped byte): relative error 2^-17 per partial,
+// 1/256 of the half-ulp of the bf16 value the finished tile is rounded to — and a quarter fewer bytes on an exchange
+// that is bound by the fabric (stamps: 48 MB out + 48 MB in per N = 4096 launch at ~8.6 TB/s each way). A row block of a
+// wave (4 accumulator quads = 16 values per lane) packs into three 16-byte words: each quad's first three values keep
+// their top three bytes, the freed low bytes carry the fourth value. Deterministic, so results stay bitwise repeatable;
+// the workgroup's own partial enters the sum unrounded. fp32-output launches exchange plain fp32.
+__device__ __forceinline__ void pack24(const f32x4& q, unsigned (&d)[3]) {
+  const unsigned u0 = __float_as_uint(q[0]) + 0x80u, u1 = __float_as_uint(q[1]) + 0x80u;
+  const unsigned u2 = __float_as_uint(q[2]) + 0x80u, u3 = __float_as_uint(q[3]) + 0x80u;
+  d[0] = __builtin_amdgcn_perm(u0, u3, 0x07060503u);     // bytes: u3.b3 | u0.b1 u0.b2 u0.b3
+  d[1] = __builtin_amdgcn_perm(u1, u3, 0x07060502u);     //        u3.b2 | u1.b1..b3
+  d[2] = __builtin_amdgcn_perm(u2, u3, 0x07060501u);     //        u3.b1 | u2.b1..b3
+}
+__device__ __forceinline__ f32x4 unpack24(unsigned d0, unsigned d1, unsigned d2) {
+  const unsigned t = __builtin_amdgcn_perm(d0, d1, 0x04000C0Cu);      // d0.b0 -> b3, d1.b0 -> b2, zeros below
+  const unsigned u3 = __builtin_amdgcn_perm(t, d2, 0x0706000Cu);      // keep b3, b2; d2.b0 -> b1; b0 = 0
+  return f32x4{__uint_as_float(d0 & 0xFFFFFF00u), __uint_as_float(d1 & 0xFFFFFF00u), __uint_as_float(d2 & 0xFFFFFF00u),
+               __uint_as_float(u3)};
+}
+
+template <int NP, bool PACK>
 __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs& a, int wid, int c, int team0, int jm,
                                                 int w, int lane, int tid, int pstride) {
   constexpr int OWN = 8 / NP;
-  const unsigned lane_off = (unsigned)(w * 32 * 1024 + lane * 16);   // this lane's 16 bytes of block 0 in a slab
+  constexpr int WPB = PACK ? 3 : 4;                       // 16-byte words per lane per row block in a slab
+  const unsigned lane_off = (unsigned)(w * 32 * 1024 + lane * 16);   // this lane's 16 bytes of word 0 of block 0 in a slab
   {
     float* my = a.slabs + (size_t)wid * SLAB_FLOATS;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(my, 0, SLAB_FLOATS * 4, 0x00020000);
 #pragma unroll
-    for (int i = OWN; i < 8; ++i)
+    for (int i = OWN; i < 8; ++i) {
+      if constexpr (PACK) {
+        unsigned d[4][3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
-                                               lane_off + (unsigned)((i * 4 + j) * 1024), 0, 16);     // aux 16 = sc1
+        for (int j = 0; j < 4; ++j) pack24(acc[i][j], d[j]);
+        const u32x4 w0 = u32x4{d[0][0], d[0][1], d[0][2], d[1][0]}, w1 = u32x4{d[1][1], d[1][2], d[2][0], d[2][1]},
+                    w2 = u32x4{d[2][2], d[3][0], d[3][1], d[3][2]};
+        __builtin_amdgcn_raw_buffer_store_b128(w0, rs, lane_off + (unsigned)((i * 3 + 0) * 1024), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(w1, rs, lane_off + (unsigned)((i * 3 + 1) * 1024), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(w2, rs, lane_off + (unsigned)((i * 3 + 2) * 1024), 0, 16);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                                 lane_off + (unsigned)((i * 4 + j) * 1024), 0, 16);   // aux 16 = sc1
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its write-through stores
   }
   __syncthreads();                                        // (also: every wave is done reading the ring)
@@ -324,27 +363,50 @@ __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs
   }
   __syncthreads();
   SK_STAMP(3);
-  u32x4 x[NP - 1][OWN * 4];
+  u32x4 x[NP - 1][OWN * WPB];
 #pragma unroll
   for (int q = 0; q < NP - 1; ++q) {
     const int p = q < c ? q : q + 1;                      // partner piece
     const float* sl = a.slabs + (size_t)((team0 + p * pstride) * ts + jm) * SLAB_FLOATS;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sl), 0, SLAB_FLOATS * 4, 0x00020000);
     // my tile row block c*OWN + i sits in partner p's register block ((c ^ p) * OWN + i)
-    const unsigned boff = lane_off + (unsigned)(((c ^ p) * OWN) * 4 * 1024);
+    const unsigned boff = lane_off + (unsigned)(((c ^ p) * OWN) * WPB * 1024);
 #pragma unroll
-    for (int b = 0; b < OWN * 4; ++b) x[q][b] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff + (unsigned)(b * 1024), 0, 16);
+    for (int b = 0; b < OWN * WPB; ++b) x[q][b] = __builtin_amdgcn_raw_buffer_load_b128(rs, boff + (unsigned)(b * 1024), 0, 16);
   }
+  if constexpr (PACK) {
 #pragma unroll
-  for (int b = 0; b < OWN * 4; ++b) {
-    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < OWN; ++i) {
+      f32x4 sum[4];
 #pragma unroll
-    for (int q = 0; q < NP - 1; ++q) {                    // pieces in K order: 0, 1, ..., NP-1 (own partial at position c)
-      if (q == c) sum += acc[b >> 2][b & 3];
-      sum += __builtin_bit_cast(f32x4, x[q][b]);
+      for (int j = 0; j < 4; ++j) sum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NP - 1; ++q) {                  // pieces in K order: 0, 1, ..., NP-1 (own partial at position c)
+        if (q == c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sum[j] += acc[i][j];
+        }
+        const u32x4 w0 = x[q][i * 3], w1 = x[q][i * 3 + 1], w2 = x[q][i * 3 + 2];
+        sum[0] += unpack24(w0[0], w0[1], w0[2]);
+        sum[1] += unpack24(w0[3], w1[0], w1[1]);
+        sum[2] += unpack24(w1[2], w1[3], w2[0]);
+        sum[3] += unpack24(w2[1], w2[2], w2[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (c == NP - 1) ? sum[j] + acc[i][j] : sum[j];
     }
-    if (c == NP - 1) sum += acc[b >> 2][b & 3];
-    acc[b >> 2][b & 3] = sum;
+  } else {
+#pragma unroll
+    for (int b = 0; b < OWN * 4; ++b) {
+      f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < NP - 1; ++q) {                  // pieces in K order: 0, 1, ..., NP-1 (own partial at position c)
+        if (q == c) sum += acc[b >> 2][b & 3];
+        sum += __builtin_bit_cast(f32x4, x[q][b]);
+      }
+      if (c == NP - 1) sum += acc[b >> 2][b & 3];
+      acc[b >> 2][b & 3] = sum;
+    }
   }
 }
 
@@ -400,9 +462,10 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
     if (s.n == 1) __syncthreads();                        // every wave is done reading the ring
     else {
       const int team0 = g - s.c * P.pstride;              // team holding piece 0 of this tile
-      if (s.n == 2) exchange_reduce<2>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
-      else if (s.n == 4) exchange_reduce<4>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
-      else exchange_reduce<8>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
+      constexpr bool PK = SK_PACK24 && sizeof(TO) == 2;  // tiles rounded to bf16 at the store: 24-bit slabs
+      if (s.n == 2) exchange_reduce<2, PK>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
+      else if (s.n == 4) exchange_reduce<4, PK>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
+      else exchange_reduce<8, PK>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
     }
     SK_STAMP(4);
     if constexpr (EPI == FVQA_EPI_SWIGLU_FWD) {

@@ -77,6 +77,11 @@ class SynthConfig:
     qav: bool = False
     video_dim: int = 768
     warm: bool = True           # non-zero gate1 so the adapter path carries gradient
+    # peaked LM-head logits (parity fixtures that pin the token argmax of the bf16 build on almost every row): the LM
+    # head is tied to the token embeddings (x 1/sqrt(dim)) and every temporal embedding is 3 x the embedding of a token,
+    # so each position's logits peak at the token (or frame token) that position holds, with a top-2 margin of about
+    # half the logit range instead of the few per cent that 32000 independent random rows leave
+    peaked: bool = False
 
     @property
     def head_dim(self) -> int:
@@ -119,7 +124,7 @@ def state_spec(cfg: SynthConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
     yield "tok_embeddings.weight", (V, D), "emb"
     yield "adapter_query.weight", (cfg.adapter_len * cfg.adapter_layer, D), "emb"
     yield "visual_proj.weight", (D, cfg.video_dim), "lin"
-    yield "temporal_emb.weight", (cfg.max_feats, D), "emb"
+    yield "temporal_emb.weight", (cfg.max_feats, D), "tied_temporal" if cfg.peaked else "emb"
     for i in range(cfg.n_layers):
         p = f"layers.{i}."
         yield p + "attention.wq.weight", (D, D), "lin"
@@ -134,7 +139,7 @@ def state_spec(cfg: SynthConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
         yield p + "attention_norm.weight", (D,), "norm"
         yield p + "ffn_norm.weight", (D,), "norm"
     yield "norm.weight", (D,), "norm"
-    yield "output.weight", (V, D), "lin"
+    yield "output.weight", (V, D), "tied_out" if cfg.peaked else "lin"
 
 
 TRAINABLE_MARKS = ("gate", "adapter", "temporal_emb", "visual_proj")   # reference llama_vqa.py:72
@@ -151,6 +156,12 @@ def make_tensor(cfg: SynthConfig, name: str, shape, kind: str, device="cpu") -> 
         return hashed_uniform(name, shape, math.sqrt(3.0), device)
     if kind == "norm":
         return hashed_uniform(name, shape, 0.1, device, offset=1.0)
+    if kind in ("tied_out", "tied_temporal"):           # SynthConfig.peaked
+        emb = hashed_uniform("tok_embeddings.weight", (cfg.vocab_size, cfg.dim), math.sqrt(3.0), device)
+        if kind == "tied_out":
+            return emb * (1.0 / math.sqrt(cfg.dim))
+        tok = [(97 + 31 * f) % cfg.vocab_size for f in range(shape[0])]
+        return 3.0 * emb[torch.tensor(tok, dtype=torch.int64, device=device)]
     if kind == "gate1":
         h = torch.arange(cfg.n_heads, dtype=torch.float32, device=device)
         g = 0.5 * (1.0 - 2.0 * (h % 2)) if cfg.warm else torch.zeros_like(h)

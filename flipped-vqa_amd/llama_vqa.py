@@ -45,7 +45,10 @@ def merge_shards(shards, n_layers):
 
 def _storage_dtype(args):
     name = str(getattr(args, "dtype", "bf16")).lower()
-    return {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[name]
+    # "fp16": the reference's own storage type (llama_vqa.py:63 builds under HalfTensor); the module then holds the shards'
+    # fp16 values exactly and the step engine converts them to bf16 when it packs the weights (llama/model.py ensure_engine)
+    return {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
+            "fp16": torch.float16, "float16": torch.float16}[name]
 
 
 def LLaMA_VQA(args, **kwargs):

@@ -43,6 +43,13 @@ CASES = {
     "7b_l2_b8_all": ("7b_l2", dict(batch_size=8, vaq=True, qav=True)),                         # C3: B=8, 24 sequences
     "7b_l2_s650_all": ("7b_l2", dict(batch_size=1, max_seq_len=650, vaq=True, qav=True)),      # C4: TVQA-shape context
     "13b_l2_all": ("13b", dict(n_layers=2, adapter_layer=2, batch_size=4, vaq=True, qav=True)),  # C5: D=5120, H=40
+    # PEAKED logits (SynthConfig.peaked: LM head tied to the embeddings, temporal embeddings tied to tokens): the reference's
+    # top-2 margin is about half the logit range on (almost) every row, so the token argmax of the bf16 build is pinned
+    # on >= 95 % of the rows instead of the 25-70 % that random LM-head rows leave outside its error band
+    "tiny_all_peaked": ("tiny", dict(vaq=True, qav=True, peaked=True)),
+    "7b_l2_b8_vqa_peaked": ("7b_l2", dict(batch_size=8, vaq=False, qav=False, peaked=True)),
+    "7b_l2_b8_all_peaked": ("7b_l2", dict(batch_size=8, vaq=True, qav=True, peaked=True)),
+    "7b_full_all_peaked": ("7b", dict(batch_size=2, vaq=True, qav=True, peaked=True)),
 }
 
 

@@ -24,7 +24,7 @@ def run_oracle(case, dtype):
     return res, lo
 
 
-@pytest.mark.parametrize("case", ["tiny_vqa", "tiny_all", "tiny_cold", "small_all"])
+@pytest.mark.parametrize("case", ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "tiny_all_peaked"])
 def test_oracle_matches_reference_fp64(case):
     g = load_golden(case)
     res, lo = run_oracle(case, torch.float64)

@@ -2,8 +2,9 @@
 (a) the golden fixtures produced from the reference itself (tests/golden, fp32-shim mode) and
 (b) the oracle run live on the same closed-form inputs. North-star tolerance: losses / logits
 within 1e-3 relative (fp32 build), token argmax bit-exact on every row whose reference top-2
-margin exceeds the error band. The bf16 build is checked against the oracle fed the same
-bf16-rounded frozen weights, with the tolerance bf16 storage allows (stated below)."""
+margin exceeds the error band. The bf16 (production) build is pinned to the SAME reference goldens
+with the tolerance bf16 storage allows (stated below) — the peaked fixtures decide its token argmax on
+>= 95 % of the rows — and to the oracle fed the same bf16-rounded frozen weights."""
 import pytest
 import torch
 
@@ -22,7 +23,8 @@ BF16_GRAD_RTOL = 8e-2
 # every BASELINE shape has a golden: C1 = 7b_full_all (full depth), C2 = 7b_l2_b8_vqa, C3 = 7b_l2_b8_all,
 # C4 = 7b_l2_s650_all, C5 = 13b_l2_all (benchmark width and batch, two layers deep)
 GOLDEN_CASES = ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "7b_l2_all", "7b_l2_vqa", "7b_full_all",
-                "7b_l2_b8_vqa", "7b_l2_b8_all", "7b_l2_s650_all", "13b_l2_all"]
+                "7b_l2_b8_vqa", "7b_l2_b8_all", "7b_l2_s650_all", "13b_l2_all",
+                "tiny_all_peaked", "7b_l2_b8_vqa_peaked", "7b_l2_b8_all_peaked", "7b_full_all_peaked"]
 # against the reference's golden the bf16 build measures (profiles/r02_parity_vs_golden.log): losses <= 3.1e-4, sampled
 # logits <= 7.5e-3 of the logit range, gradients <= 2.0e-2; the bounds below leave about 2.5x
 BF16_TOL = dict(loss=5e-3, logits=2e-2, layer=3e-2, grad=5e-2)
@@ -50,19 +52,30 @@ def test_fp32_step_matches_reference_golden(case):
     _free(model)
 
 
-@pytest.mark.parametrize("case", ["small_all", "7b_l2_all", "7b_full_all", "7b_l2_b8_vqa", "7b_l2_b8_all",
-                                  "7b_l2_s650_all", "13b_l2_all"])
+# least fraction of rows whose token argmax the bf16 build must DECIDE (reference top-2 margin above 8 x the measured
+# logit error) — and get right. Peaked fixtures (LM head tied to the embeddings): >= 95 %. Random LM-head rows leave
+# margins of a few per cent of the logit range: the floors below are 0.8 x the fractions measured in round 2
+# (profiles/r02_parity_vs_golden.log: 94/189 ... 700/1016; the full-depth case 64/254), so the check cannot silently
+# decay to "no row decided".
+BF16_MIN_DECIDED = {"small_all": 0.40, "7b_l2_all": 0.49, "7b_full_all": 0.20, "7b_l2_b8_vqa": 0.55, "7b_l2_b8_all": 0.48,
+                    "7b_l2_s650_all": 0.47, "13b_l2_all": 0.49,
+                    "7b_l2_b8_vqa_peaked": 0.95, "7b_l2_b8_all_peaked": 0.95, "7b_full_all_peaked": 0.95}
+
+
+@pytest.mark.parametrize("case", list(BF16_MIN_DECIDED))
 def test_bf16_step_against_reference_golden(case):
     """The PRODUCTION build (bf16 storage, MFMA attention) against the reference's own results at the benchmark's
     shapes: losses within 5e-3, sampled logits within 2e-2 of the logit range, gradients within 5e-2 (max-abs over
     max-abs / norms; bf16 keeps 8 mantissa bits and the frozen weights themselves are rounded), and the token argmax
-    equal on every row whose reference top-2 margin exceeds 8 x the measured logit error."""
+    equal on every row whose reference top-2 margin exceeds 8 x the measured logit error — at least BF16_MIN_DECIDED of
+    the rows: >= 95 % on the peaked fixtures at C2's and C3's shapes and at full depth."""
     pname, over = CASES[case]
     cfg = synth.preset(pname, **over)
     model, _ = build_model(cfg, torch.bfloat16)
     batch = synth.make_batch(cfg, seed=0)
     losses, grads, logits, layer_out = run_step(model, batch)
-    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=BF16_LOSS_RTOL, tol=BF16_TOL)
+    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=BF16_LOSS_RTOL, tol=BF16_TOL,
+                              min_decided=BF16_MIN_DECIDED[case])
     print(case, {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
     model._engine.check_gemm_error()
     _free(model)

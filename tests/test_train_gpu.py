@@ -133,6 +133,87 @@ def test_checkpoint_roundtrip(tmp_path):
     assert torch.equal(opt2.exp_avg, opt.exp_avg) and opt2.step_dev.item() == opt.step_dev.item()
 
 
+def _write_meta_checkpoint(model_dir, cfg, n_shards=2):
+    """What the reference reads (llama_vqa.py:8-22): params.json + `n_shards` model-parallel fp16 shards in Meta's
+    layout (column-parallel tensors cut on dim 0, wo / w2 / tok_embeddings on dim 1, norms replicated, plus the
+    `rope.freqs` buffer the reference's strict=False load ignores). Values: the closed-form frozen weights."""
+    from llama_vqa import _SPLIT_DIM
+    os.makedirs(model_dir, exist_ok=True)
+    sd = synth.state_dict(cfg)
+    shards = [dict() for _ in range(n_shards)]
+    for name, t in sd.items():
+        if synth.is_trainable(name):
+            continue                                       # LLaMA checkpoints hold no adapter / gate / projection
+        short = name.split(".", 2)[2] if name.startswith("layers.") else name
+        dim = _SPLIT_DIM[short]
+        pieces = [t.half().clone() for _ in range(n_shards)] if dim < 0 else [c.half().contiguous() for c in t.chunk(n_shards, dim)]
+        for sh, pc in zip(shards, pieces):
+            sh[name] = pc
+    for i, sh in enumerate(shards):
+        sh["rope.freqs"] = torch.arange(cfg.head_dim // 2, dtype=torch.float16)
+        torch.save(sh, os.path.join(model_dir, f"consolidated.{i:02d}.pth"))
+    with open(os.path.join(model_dir, "params.json"), "w") as f:
+        json.dump(cfg.params_json(), f)
+    return sd
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_llama_vqa_from_sharded_fp16_checkpoint_end_to_end(tmp_path, dtype):
+    """The REAL loading path (reference llama_vqa.py:15-76), disk to step: params.json + a 2-shard fp16 Meta checkpoint
+    -> LLaMA_VQA(args) (no random_init: glob, merge, strict=False load, freeze policy) -> one training step on the
+    HIP path, against the oracle fed the SAME weights (fp16-rounded as stored; bf16-rounded on top for the bf16
+    storage builds). dtype 'fp16' holds the shards' values exactly in the module, as the reference does, and takes
+    the fp16 -> bf16 conversion at pack time."""
+    import types
+    from llama_vqa import LLaMA_VQA
+    cfg = synth.preset("tiny", vaq=True, qav=True)
+    sd = _write_meta_checkpoint(tmp_path / "7B", cfg)
+    args = types.SimpleNamespace(
+        llama_model_path=str(tmp_path) + "/", model="7B", max_seq_len=cfg.max_seq_len, adapter_len=cfg.adapter_len,
+        adapter_layer=cfg.adapter_layer, max_feats=cfg.max_feats, bias=cfg.bias, tau=cfg.tau, vaq=True, qav=True,
+        audio=False, audio_only=False, audio_merge="none", debug=False, synthetic=True, vocab_size=cfg.vocab_size,
+        dtype=dtype, accum_iter=1, weight_decay=0.14)
+    model = LLaMA_VQA(args)                                  # reads the shards: no random_init
+    model.to("cuda")
+    store = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype]
+    assert not any(n.startswith("rope") for n, _ in model.named_parameters())
+    for n, p in model.named_parameters():
+        if synth.is_trainable(n):
+            assert p.requires_grad and p.dtype == torch.float32, n
+        else:
+            assert not p.requires_grad and p.dtype == store, (n, p.dtype)
+            want = sd[n].half().to(store)                    # the shard values, merged
+            assert torch.equal(p.detach().cpu(), want), f"{n}: merged shard values differ"
+    with torch.no_grad():                                    # trainables are not in a LLaMA checkpoint: known values
+        own = dict(model.named_parameters())
+        for n, t in sd.items():
+            if synth.is_trainable(n):
+                own[n].copy_(t)
+    batch = synth.make_batch(cfg, seed=5)
+    from tests.gpu_util import run_step
+    losses, grads, _, _ = run_step(model, batch)
+    if dtype != "fp32":                                      # what the kernels compute on: bf16 storage
+        assert model.tok_embeddings.weight.dtype == torch.bfloat16
+        assert all(p.dtype == torch.bfloat16 for n, p in model.named_parameters() if not synth.is_trainable(n))
+    ref_sd = {}
+    for n, t in sd.items():
+        if synth.is_trainable(n):
+            ref_sd[n] = t
+        else:
+            r = t.half()
+            ref_sd[n] = (r.to(torch.bfloat16) if dtype != "fp32" else r).float()
+    ref = ref_cpu.RefModel(cfg, ref_sd, dtype=torch.float64).step(batch)
+    ltol, gtol = (1e-3, 1e-3) if dtype == "fp32" else (2e-2, 8e-2)
+    for t in ref["tasks"]:
+        r = float(ref["losses"][t])
+        assert abs(losses[t] - r) / abs(r) < ltol, (dtype, t, losses[t], r)
+    for n, g in ref["grads"].items():
+        gn = float(g.norm())
+        if gn > 0:
+            assert float((grads[n].double() - g).norm()) / gn < gtol, (dtype, n)
+    model._engine.check_gemm_error()
+
+
 def test_gates_of_skipped_layers_are_left_alone():
     """adapter_layer < n_layers: the engine skips the first layers (reference llama/model.py:338), their gates get no
     gradient in the reference (.grad is None -> torch AdamW neither decays nor moves them)."""

@@ -65,6 +65,9 @@ SK_SHAPES = [
     (1024, 22016, 512),    # 86 on 64 teams: one whole round + 22 tiles split 2
     (3072, 2816, 1024),    # 12 m tiles = 2 m groups of 6
     (200, 264, 128),       # N % 256 != 0, M < 256
+    (1024, 12288, 4096),   # QKV: 48 team-tiles of 256 columns leave 64 CUs idle -> 64 team-tiles of 192 columns (bf16)
+    (1024, 11008, 512),    # W2^T's outputs: 58 team-tiles of 192 columns, the last one 64 columns wide
+    (700, 12288, 512),     # 192-column tiles with a ragged last m tile
 ]
 
 

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from fvqa import ops, _lib  # noqa: E402
 
 dev = "cuda"
-SHAPES = [("qkv_fwd", 1024, 12288, 4096), ("wo_fwd", 1024, 4096, 4096), ("w13_fwd", 1024, 22016, 4096),
+SHAPES = [("qkv_fwd", 1024, 12288, 4096), ("wo_fwd", 1024, 4096, 4096), ("w13_fwd", 1024, 22016, 4096), ("w2_fwd", 1024, 4096, 11008), ("qkvt_bwd", 1024, 4096, 12288),
           ("w2t_bwd", 1024, 11008, 4096), ("w13t_bwd", 1024, 4096, 22016)]
 lib = _lib.load()
 need = int(lib.fvqa_gemm_sk_workspace())

@@ -36,6 +36,7 @@ SIGNATURES = {
     "fvqa_swiglu_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fvqa_attn_rope_fused": (_i, [_i]),
     "fvqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_attn_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "fvqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_visual_proj_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

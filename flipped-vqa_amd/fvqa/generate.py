@@ -3,8 +3,8 @@
 The reference decodes greedily by re-running the WHOLE sequence through all layers once per generated token
 and per sample (31 forwards of (1, S) per sample, no KV cache). Here the prompt is run once for the whole
 batch (the training forward, which already keeps every layer's q/k/v in the arena = the KV cache); each
-further token recomputes only its own row per sample: RMSNorm -> QKV row -> (RoPE) -> the gated attention
-kernel over the cached keys -> WO -> SwiGLU MLP -> LM head row -> argmax. Causality makes this identical to
+further token recomputes only its own row per sample: RMSNorm -> QKV row -> the one-query-row gated attention
+kernel over the cached keys (RoPE inside; the row's k, v join the cache) -> WO -> SwiGLU MLP -> LM head row -> argmax. Causality makes this identical to
 the reference's re-forward: rows before the new token do not change, rows after it are never read.
 The answer is then matched to the choices by cosine similarity of mean token embeddings, with the
 reference's quirks kept (choices padded with id 0 before averaging, llama/model.py:566-575)."""
@@ -43,12 +43,11 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
         fused = ops.attn_rope_fused(eng.dtype)
         ids = ids_all[:, 0].to(dev).clone()
         prefix = torch.as_tensor([int(p) for p in data["prefix_index"]["vqa"]], device=dev)
-        seq0 = torch.arange(B, device=dev) * S
         pos = prefix - 1                                    # start_idx of the first iteration
         logits = ar.logits.view(B, S, V)
         pred = logits[torch.arange(B, device=dev), pos.clamp(0, S - 1)].argmax(-1)
         e = lambda *s, dtype=eng.dtype: torch.empty(*s, dtype=dtype, device=dev)  # noqa: E731
-        xn, hn, h, x2 = e(B, D), e(B, D), e(B, D), e(B, D)
+        xn, hn, h, x2, o_row = e(B, D), e(B, D), e(B, D), e(B, D), e(B, D)
         qkv_row, ab, z = e(B, 3 * D), e(B, 2 * Hf), e(B, Hf)
         lg = e(B, V, dtype=torch.float32)
         for _ in range(n_new):
@@ -56,20 +55,16 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
             tgt = (pos + 1).clamp(max=S - 1)
             ids[torch.arange(B, device=dev), tgt] = torch.where(ok, pred, ids[torch.arange(B, device=dev), tgt])
             pos = tgt
-            rows = seq0 + pos
             x = pk.emb[ids[torch.arange(B, device=dev), pos]].contiguous()
             for i in range(L):
                 ops.rmsnorm_fwd(x, pk.an[i], xn, None, eng.eps, rows=B)
                 ops.gemm_nt(xn, pk.wqkv[i], qkv_row)
                 g1, g2 = m.gate_views(i)
-                if fused:
-                    ar.qkv[i].index_copy_(0, rows, qkv_row)
-                    ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, B, S, H, Dh, A, F,
-                                 rope=(eng.cos, eng.sin))
-                else:                                       # vector build: rows are stored rotated
-                    ar.qkv[i].index_copy_(0, rows, _rope_rows(qkv_row, eng.cos[pos], eng.sin[pos], D, Dh))
-                    ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, B, S, H, Dh, A, F)
-                ops.gemm_nt(ar.o[i].index_select(0, rows), pk.wo[i], h, residual=x)
+                # the new row against the cached keys / values (+ adapter prefix); its k, v join the cache. The bf16
+                # build caches RAW keys (rotated on the fly), the fp32 vector build rotated ones.
+                ops.attn_decode(qkv_row, ar.qkv[i], o_row, g1, g2, vstart, pos, (eng.cos, eng.sin), B, S, H, Dh, A, F,
+                                cache_rotated=not fused)
+                ops.gemm_nt(o_row, pk.wo[i], h, residual=x)
                 ops.rmsnorm_fwd(h, pk.fn[i], hn, None, eng.eps, rows=B)
                 ops.gemm_nt(hn, pk.w13[i], ab)
                 ops.swiglu_fwd(ab, z, B, Hf)
@@ -82,18 +77,6 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
     finally:
         eng._gen_arena = eng._arena
         eng.tasks, eng.n_streams, eng._arena, eng._vstart = saved
-
-
-def _rope_rows(qkv_row: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, D: int, Dh: int) -> torch.Tensor:
-    """RoPE of the q and k parts of (B, 3D) rows at per-row positions (cos/sin: (B, Dh/2))."""
-    out = qkv_row.clone()
-    B = qkv_row.shape[0]
-    qk = qkv_row[:, :2 * D].float().view(B, -1, Dh // 2, 2)
-    c, s = cos[:, None, :], sin[:, None, :]
-    ev, od = qk[..., 0], qk[..., 1]
-    rot = torch.stack([ev * c - od * s, ev * s + od * c], dim=-1).view(B, 2 * D)
-    out[:, :2 * D] = rot.to(qkv_row.dtype)
-    return out
 
 
 @torch.no_grad()

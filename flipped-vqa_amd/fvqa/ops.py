@@ -385,6 +385,26 @@ def attn_fwd(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, Dh, A, F, 
     return o
 
 
+def attn_decode(qkv_row, qkv_cache, o_row, gate1, gate2, vstart, pos, rope, n_seq, S, H, Dh, A, F, cache_rotated: bool):
+    """One new token per sequence (generation path): attention of the new row over the cached keys / values + the
+    adapter prefix; the new token's k, v are stored into cache row n*S + pos[n]. qkv_row holds RAW projections."""
+    _dev(qkv_row, qkv_cache, o_row, gate1, gate2, vstart, pos)
+    cos_t, sin_t = _rope_tables(rope, S, Dh, "attn_decode")
+    D = _attn_shapes(qkv_cache, n_seq, S, H, Dh, A)
+    _need(cos_t is not None, "attn_decode: rope tables")
+    _need(qkv_row.dtype == qkv_cache.dtype == o_row.dtype, "attn_decode: dtype")
+    _need(tuple(qkv_row.shape) == (n_seq, 3 * D) and tuple(o_row.shape) == (n_seq, D), "attn_decode: row shapes")
+    _need(pos.dtype == torch.int64 and pos.numel() == n_seq, "attn_decode: pos")
+    _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "attn_decode: vstart")
+    for t in (gate1, gate2):
+        _need(t.dtype == torch.float32 and t.numel() == H, "attn_decode: gate shape")
+    rc = _lib.load().fvqa_attn_decode(_ptr(qkv_row), _ptr(qkv_cache), _ptr(o_row), _ptr(gate1), _ptr(gate2),
+                                      _ptr(vstart), _ptr(pos), _ptr(cos_t), _ptr(sin_t), n_seq, S, H, Dh, A, F,
+                                      1 if cache_rotated else 0, dt_code(qkv_row.dtype), _stream())
+    _lib.check(rc, "fvqa_attn_decode")
+    return o_row
+
+
 def attn_bwd_workspace(n_seq, S, H, Dh, A) -> int:
     return int(_lib.load().fvqa_attn_bwd_workspace(n_seq, S, H, Dh, A))
 

@@ -166,6 +166,17 @@ int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const fl
                   const float* gate2, const int32_t* vstart, const float* cos_t, const float* sin_t,
                   int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
                   int dtype, void* stream);
+/* One-query-row attention of the generation path (llama/model.py:428-470 re-runs the whole sequence per new token; this
+ * evaluates Attention.forward :87-128 at the new row only). qkv_row (n_seq, 3*dim): RAW q | k | v projections of each
+ * sequence's new token, whose position is pos[n] (int64, device). qkv_cache: the layer's (n_seq*S + A, 3*dim) buffer of
+ * fvqa_attn_fwd, holding the keys / values of positions < pos[n] (RAW k when cache_rotated == 0 — the bf16 build, rotated
+ * on the fly —, ROTATED k when 1 — the fp32 build) and the adapter rows; the kernel rotates the new q and k with the
+ * tables, writes o_row (n_seq, dim) and stores the new token's k (in the cache's convention) and v into cache row
+ * n*S + pos[n]. seq_len <= 4096. */
+int fvqa_attn_decode(const void* qkv_row, void* qkv_cache, void* o_row, const float* gate1, const float* gate2,
+                     const int32_t* vstart, const int64_t* pos, const float* cos_t, const float* sin_t, int n_seq,
+                     int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats, int cache_rotated,
+                     int dtype, void* stream);
 /* workspace bytes fvqa_attn_bwd needs (fp32 partials for the batch-summed adapter k/v
  * gradients and the per-head gate sums). Its FIRST 1024 BYTES are integer arrival counters of the
  * fused bf16 backward: the caller zeroes them once after allocating the workspace; every call

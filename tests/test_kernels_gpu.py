@@ -456,6 +456,49 @@ def test_attention_fused_rope_bf16(N, S, H, vstart):
     assert rel(dqf[N * S:, 2 * D:], dav.reshape(A, D)) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cache_rotated", [False, True])
+@pytest.mark.parametrize("N,S,H,vstart", [(3, 128, 2, [19, -1, 40]), (2, 300, 1, [8, -1])])
+def test_attention_decode_row(dtype, cache_rotated, N, S, H, vstart):
+    """One-query-row attention of the generation path (fvqa_attn_decode): for a new token at position p[n] of each
+    sequence — its RAW q, k, v in qkv_row, keys / values of positions < p in the cache (raw k, or rotated k) —
+    the output row equals row p of the full-sequence oracle on the rotated operands (llama/model.py:87-128 at that
+    row), and the token's k (in the cache's convention) and v land in cache row n*S + p."""
+    A, F = 10, 10
+    qkv, g1, g2, vs, Dh, D = _attn_case(dtype, N, S, H, A, F, vstart, seed=S + 7)
+    cos, sin = ref_cpu.rope_tables(2 * S, Dh, torch.float32)
+    pos = torch.tensor([S - 1, 5, S // 2][:N], dtype=torch.int64)
+    q = qkv[: N * S, :D].double().view(N, S, H, Dh)
+    k = qkv[: N * S, D:2 * D].double().view(N, S, H, Dh)
+    v = qkv[: N * S, 2 * D:].double().view(N, S, H, Dh)
+    ak = qkv[N * S:, D:2 * D].double().view(A, H, Dh)
+    av = qkv[N * S:, 2 * D:].double().view(A, H, Dh)
+    c64, s64 = cos[:S].double(), sin[:S].double()
+    qr, kr = ref_cpu.rope_apply(q, c64, s64), ref_cpu.rope_apply(k, c64, s64)
+    o_ref, _ = ref_cpu.attn_fwd(qr, kr, v, ak, av, g1.double(), g2.double(), vstart, F)
+    # the cache: raw or rotated keys below the new position; the new token's row poisoned (the kernel must fill it)
+    cache = qkv.clone()
+    if cache_rotated:
+        cache[: N * S, D:2 * D] = kr.reshape(N * S, D).to(dtype)
+    rows = torch.arange(N) * S + pos
+    qkv_row = qkv[rows].clone()                               # RAW projections of the new tokens
+    cache[rows] = float("nan")
+    cache_d = dev(cache)
+    o_row = torch.empty(N, D, dtype=dtype, device=DEV)
+    ops.attn_decode(dev(qkv_row), cache_d, o_row, dev(g1), dev(g2), dev(vs), dev(pos), (dev(cos), dev(sin)),
+                    N, S, H, Dh, A, F, cache_rotated=cache_rotated)
+    want = torch.stack([o_ref[n, int(pos[n])] for n in range(N)]).reshape(N, D)
+    assert rel(o_row, want) < tol(dtype, 3e-5, 1e-2)
+    got = cache_d.cpu()
+    want_k = (kr if cache_rotated else k).reshape(N * S, D)[rows]
+    assert rel(got[rows][:, D:2 * D], want_k) < tol(dtype, 1e-6, 8e-3)
+    assert torch.equal(got[rows][:, 2 * D:], qkv[rows][:, 2 * D:])
+    # nothing else in the cache moved
+    keep = torch.ones(N * S + A, dtype=torch.bool)
+    keep[rows] = False
+    assert torch.equal(got[keep], cache[keep])
+
+
 def test_attention_rope_tables_rejected_by_vector_build():
     N, S, H, A, F = 1, 32, 1, 10, 10
     qkv, g1, g2, vs, Dh, D = _attn_case(torch.float32, N, S, H, A, F, [5], seed=4)

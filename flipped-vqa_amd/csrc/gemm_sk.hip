@@ -12,7 +12,7 @@
 //             WRITE-THROUGH (sc1) stores in register-image order (1 KiB contiguous per wave instruction = whole
 //             128-byte lines), s_waitcnt vmcnt(0) in EVERY wave, workgroup barrier, then ONE lane stores the launch
 //             epoch to the workgroup's flag with an agent-scope atomic (sc1) store;
-//   consumer: ONE lane polls each partner's flag (relaxed agent-scope sc1 load, bounded spin), workgroup barrier, then
+//   consumer: one lane per partner polls that partner's flag (relaxed agent-scope sc1 load, bounded spin), workgroup barrier, then
 //             every wave reads the partners' slabs with sc1 loads ONLY (they bypass this CU's L1; -DFVQA_SK_ACQUIRE
 //             adds the agent-scope acquire fence the general recipe has).
 // Results do not depend on dispatch order or XCD placement; every sum runs in piece order 0..s-1, so outputs are
@@ -350,10 +350,10 @@ __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs
   __syncthreads();                                        // (also: every wave is done reading the ring)
   SK_STAMP(2);
   const int ts = a.plan.ts;
-  if (tid == 0) {
-    __hip_atomic_store(a.sync + 1 + wid, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int p = 0; p < NP; ++p)        // (a lost partner has raised the error word: the others are not waited for)
-      if (p != c && !wait_epoch(a.sync + 1 + (team0 + p * pstride) * ts + jm, a.epoch, a.sync)) break;
+  if (tid < NP - 1) {                   // lanes 0 .. NP-2 of wave 0: one partner's flag each, polled side by side
+    if (tid == 0) __hip_atomic_store(a.sync + 1 + wid, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int p = tid < c ? tid : tid + 1;                // (a lost partner raises the error word after its bounded wait)
+    (void)wait_epoch(a.sync + 1 + (team0 + p * pstride) * ts + jm, a.epoch, a.sync);
 #ifdef FVQA_SK_ACQUIRE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // not needed while EVERY load of a partner's slab is an sc1 load
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

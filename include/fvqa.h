@@ -86,8 +86,14 @@ int fvqa_gemm_nt_swiglu_fwd_st(const void* A, const void* B13, void* st, void* z
  * Its FIRST 4096 BYTES are the epoch flags of the persistent kernel (csrc/gemm_sk.hip): the caller zeroes them ONCE
  * after allocating the buffer (256-byte aligned); no call ever needs them reset. One workspace serves one stream at
  * a time. The first 64-bit word is an ERROR word: a workgroup whose bounded wait (~1 s) for a partner of a split tile
- * ran out sets it to non-zero and lets the grid drain — the outputs of that launch are then invalid; callers read it
- * back at a convenient point (fvqa.ops.gemm_error / StepEngine.check_gemm_error do). */
+ * ran out sets it to non-zero and lets the grid drain — the outputs of that launch are then invalid. It is sticky; hand
+ * its address to fvqa_grad_unscale_norm (the optimizer step of such a step is then skipped on the device) and read it
+ * back at a convenient point (fvqa.ops.gemm_error / StepEngine.check_gemm_error; engine.train_one_epoch every iteration).
+ * The bounded wait presumes that every workgroup of the grid is resident: the kernel asks for all 160 KiB of a CU's LDS and
+ * launches at most one workgroup per CU of the CURRENT device, so the device must be this process's alone while a launch
+ * runs (another process's persistent grid, or any kernel holding LDS on many CUs, can displace a partner: a 1 s stall and
+ * the error word, not a hang). Launches into a stream under capture are refused (FVQA_EINVAL): the epoch number is a
+ * host-side argument, and a replayed graph would reuse it. */
 size_t fvqa_gemm_workspace(int M, int N, int K, int dtype);
 /* The persistent kernel (variant 0 for M >= 192, N >= 256, N % 8 == 0, no tail rows; variant 13 forces it): a grid of
  * at most one workgroup per CU walks whole 256x256 output tiles, or — outputs with few tiles — one K range of a tile
@@ -307,7 +313,7 @@ typedef struct fvqa_layer_plan {
   float* lse_t;
   void* h;                   /* (L, R, D)   */
   void* ab;                  /* (L, R, 2Hf), AB16 */
-  void* xn;                  /* (Ra, D) scratch */
+  void* xn;                  /* (R, D) scratch */
   void* hn;                  /* (R, D)  scratch */
   void* z;                   /* (R, Hf) scratch */
   void* xnf;                 /* (R, D) final-norm output */

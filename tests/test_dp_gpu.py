@@ -112,5 +112,9 @@ def test_bench_self_launches_two_ranks_from_a_plain_shell(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["scaling"] == "weak"
+    # the N > 1 line says what its exchange step cost: backend, ranks, bytes and device time of the gradient all-reduce
+    c = d["comm"]
+    assert c["rccl_ranks"] == 2 and c["allreduce_calls_per_step"] == 1.0 and c["allreduce_ms"] > 0
+    assert c["allreduce_bytes"] > 12 * 2 ** 20
     if torch.cuda.device_count() < 2:
-        assert d.get("rehearsal") is True
+        assert d.get("rehearsal") is True and c["backend"] == "gloo"

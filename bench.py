@@ -261,7 +261,29 @@ def main():
         print(f"[bench] model built in {time.time() - t_build:.1f}s; "
               f"{torch.cuda.memory_allocated() / 2**30:.1f} GiB allocated", file=sys.stderr, flush=True)
 
+    rehearsal_lock = None
+    if world > 1 and os.environ.get("FVQA_BENCH_REHEARSAL") == "1":
+        # Rehearsal (several ranks on ONE GPU, control flow only): the persistent GEMM needs the device to itself
+        # (include/fvqa.h: one workgroup per CU, partners wait for each other), so two ranks' forward / backward must not
+        # share the chip — they take turns under a file lock, released before the gradient all-reduce (where every rank
+        # has to be present). On real multi-GPU runs every rank owns its device and none of this exists.
+        import fcntl
+        import tempfile
+        rehearsal_lock = open(os.path.join(tempfile.gettempdir(),
+                                           f"fvqa_bench_{os.environ.get('MASTER_PORT', '0')}.lock"), "w")
+        sync_grads = net.sync_grads
+
+        def _turn_over():
+            torch.cuda.synchronize()
+            fcntl.flock(rehearsal_lock, fcntl.LOCK_UN)
+            return sync_grads()
+
+        opt.grad_sync = _turn_over
+
     def one_step(i):
+        if rehearsal_lock is not None:
+            import fcntl
+            fcntl.flock(rehearsal_lock, fcntl.LOCK_EX)
         opt.zero_grad()
         vqa, vaq, qav = net(batches[i % n_batches])
         loss = vqa + vaq + qav

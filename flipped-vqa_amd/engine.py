@@ -33,7 +33,7 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
     n_iter = len(data_loader)
     accum = args.accum_iter
     optimizer.zero_grad()
-    host_vals, copied, host_found = None, None, None
+    host_vals, copied = None, None
 
     for it, data in enumerate(log.log_every(data_loader, n_iter // 4, f"Epoch: [{epoch}]")):
         boundary_start = it % accum == 0
@@ -43,30 +43,27 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
 
         vqa_loss, vaq_loss, qav_loss = model(data)
         loss = vqa_loss + vaq_loss + qav_loss
+        # the three losses and — riding in the same transfer, at no cost of its own — the found-inf word the loss scaler
+        # left on the device in the PREVIOUS iteration (2 = the GEMM error word was set: include/fvqa.h)
+        found_dev = getattr(loss_scaler, "_found", None)
+        prev_found = found_dev.reshape(()).float() if torch.is_tensor(found_dev) and found_dev.device == vqa_loss.device \
+            else torch.zeros((), dtype=torch.float32, device=vqa_loss.device)
         vals_dev = torch.stack([vqa_loss.reshape(()).float(), vaq_loss.reshape(()).float(),
-                                qav_loss.reshape(()).float()])
+                                qav_loss.reshape(()).float(), prev_found])
         if vals_dev.is_cuda:                                  # one asynchronous D2H copy into pinned memory
             if host_vals is None:
-                host_vals, copied = torch.empty(3, dtype=torch.float32, pin_memory=True), torch.cuda.Event()
+                host_vals, copied = torch.empty(4, dtype=torch.float32, pin_memory=True), torch.cuda.Event()
             host_vals.copy_(vals_dev, non_blocking=True)
             copied.record()
 
         loss_scaler(loss / accum, optimizer, parameters=model.parameters(), update_grad=boundary_end)
-        found_dev = getattr(loss_scaler, "_found", None)
-        if boundary_end and vals_dev.is_cuda and found_dev is not None:
-            # the step's found-inf word (2 = GEMM error word set, include/fvqa.h), read one iteration late: no wait here
-            if host_found is None:
-                host_found = torch.zeros(1, dtype=torch.float32, pin_memory=True)
-            host_found.copy_(found_dev, non_blocking=True)
 
         if vals_dev.is_cuda:
             copied.synchronize()                              # the forward has finished; the backward is queued
             vals = host_vals.tolist()
-            # the previous iteration's copy of found_inf has landed (same stream, queued before this forward); the word is
-            # sticky, so whichever iteration's value is seen, 2 means a step ran on a timed-out split-K exchange
-            if host_found is not None and float(host_found[0]) == 2.0:
-                raise RuntimeError("fvqa: a split-K exchange of the persistent GEMM timed out (found_inf = 2): that "
-                                   "optimizer step was skipped and the results of its launch are invalid")
+            if vals[3] == 2.0:                                # (sticky: the error word stays set until someone clears it)
+                raise RuntimeError("fvqa: a split-K exchange of the persistent GEMM timed out (found_inf = 2): the "
+                                   "previous optimizer step was skipped and the results of its launches are invalid")
         else:
             vals = vals_dev.tolist()
         loss_value = vals[0] + vals[1] + vals[2]

@@ -102,6 +102,34 @@ def test_train_one_epoch_stops_on_a_non_finite_loss(capsys):
     assert opt.step_dev.item() <= 1.0                        # it stopped at the FIRST iteration
 
 
+def test_train_one_epoch_raises_on_a_set_gemm_error_word():
+    """A timed-out split-K exchange (sticky error word of the stream's GEMM workspace) must end the epoch at the next
+    iteration, not after a whole epoch of skipped steps: the step it hits is a no-op on the device (found_inf = 2), and the
+    word reaches the host in the NEXT iteration's loss transfer (no device-to-host read of its own)."""
+    from fvqa import ops
+    cfg = synth.preset("7b_l2", batch_size=2, vaq=True, qav=True)
+    model, args = build_model(cfg, torch.bfloat16)
+    opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=0.01, betas=(0.9, 0.95),
+                     flat=model.flat_params())
+    args.accum_iter, args.lr, args.warmup_epochs, args.epochs = 1, 0.02, 0, 1
+    scaler = misc.NativeScalerWithGradNormCount()
+    loader = synth.SyntheticLoader(cfg, 4)
+    engine.train_one_epoch(model, synth.SyntheticLoader(cfg, 2), opt, 0, scaler, args=args)    # a clean epoch first
+    torch.cuda.synchronize()
+    steps0, p0 = opt.step_dev.item(), model.flat_params().flat.clone()
+    word = ops.gemm_error_word(model.flat_params().flat.device)
+    assert word is not None
+    word.view(torch.int64)[0] = 1
+    try:
+        with pytest.raises(RuntimeError, match="split-K exchange"):
+            engine.train_one_epoch(model, loader, opt, 1, scaler, args=args)
+        torch.cuda.synchronize()
+        assert opt.step_dev.item() == steps0                 # no step was applied while the word was set
+        assert torch.equal(model.flat_params().flat, p0)
+    finally:
+        word.view(torch.int64)[0] = 0
+
+
 def test_switched_off_losses_are_the_reference_placeholders():
     """vaq / qav off: `tensor([0])` int64 on the model's device (llama/model.py:302), so that the summed loss has shape [1]."""
     cfg = synth.preset("tiny", vaq=False, qav=False)

@@ -299,6 +299,12 @@ def main():
     for i in range(a.warmup):
         one_step(i)
     fence()
+    if os.environ.get("FVQA_BENCH_INJECT_GEMM_ERROR") == "1":
+        # test hook (tests/test_bench_gpu.py): what a timed-out split-K exchange leaves behind — the line must come out
+        # invalid and the process must fail
+        w_ = ops.gemm_error_word(dev)
+        if w_ is not None:
+            w_.view(torch.int64)[0] = 1
     if world > 1:
         net.comm_events = []                 # an event pair around every gradient all-reduce of the timed steps
     t0 = time.perf_counter()

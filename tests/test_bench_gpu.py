@@ -30,3 +30,18 @@ def test_bench_emits_the_contract_line():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_bench_fails_on_a_set_gemm_error_word():
+    """A timed-out split-K exchange during the run (the workspace's sticky error word, injected after the warm-up) must
+    not produce a valid-looking line: every optimizer step of the timed region is skipped on the device, the JSON says
+    `invalid`, the exit status is non-zero."""
+    env = dict(os.environ, FVQA_BENCH_INJECT_GEMM_ERROR="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n_layers", "2", "--steps", "3", "--warmup",
+                        "1", "--no_cpu_baseline"], capture_output=True, text=True, timeout=500, cwd=ROOT, env=env)
+    assert r.returncode != 0, r.stdout[-1000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "split-K exchange" in d["invalid"]

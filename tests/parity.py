@@ -30,6 +30,8 @@ CASES = {
     "7b_l2_b8_vqa_peaked": ("7b_l2", dict(batch_size=8, vaq=False, qav=False, peaked=True)),
     "7b_l2_b8_all_peaked": ("7b_l2", dict(batch_size=8, vaq=True, qav=True, peaked=True)),
     "7b_full_all_peaked": ("7b", dict(batch_size=2, vaq=True, qav=True, peaked=True)),
+    "7b_l2_s650_all_peaked": ("7b_l2", dict(batch_size=1, max_seq_len=650, vaq=True, qav=True, peaked=True)),
+    "13b_l2_all_peaked": ("13b", dict(n_layers=2, adapter_layer=2, batch_size=4, vaq=True, qav=True, peaked=True)),
 }
 
 

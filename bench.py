@@ -233,7 +233,9 @@ def main():
         kw["n_layers"] = a.n_layers
         args.adapter_layer = a.n_layers
     t_build = time.time()
-    model = LLaMA_VQA(args, **kw)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # the factory prints the reference's banner; stdout carries ONE JSON line
+        model = LLaMA_VQA(args, **kw)
     model.to(dev)
     p = model.params
     eff = a.batch_size * world

@@ -50,6 +50,11 @@ CASES = {
     "7b_l2_b8_vqa_peaked": ("7b_l2", dict(batch_size=8, vaq=False, qav=False, peaked=True)),
     "7b_l2_b8_all_peaked": ("7b_l2", dict(batch_size=8, vaq=True, qav=True, peaked=True)),
     "7b_full_all_peaked": ("7b", dict(batch_size=2, vaq=True, qav=True, peaked=True)),
+    # BASELINE configs[1] (C2, the benchmarked workload) at FULL depth: 32 layers, B=8, S=128, VQA loss
+    "7b_full_b8_vqa_peaked": ("7b", dict(batch_size=8, vaq=False, qav=False, peaked=True)),
+    # C4's context length (S = 650, TVQA shape) at FULL depth: 32 layers, B=1, VQA loss (the three-stream case of
+    # configs[3] at this depth needs more than the 64 GiB the fp32 reference has in the build container)
+    "7b_full_s650_vqa_peaked": ("7b", dict(batch_size=1, max_seq_len=650, vaq=False, qav=False, peaked=True)),
     "7b_l2_s650_all_peaked": ("7b_l2", dict(batch_size=1, max_seq_len=650, vaq=True, qav=True, peaked=True)),
     "13b_l2_all_peaked": ("13b", dict(n_layers=2, adapter_layer=2, batch_size=4, vaq=True, qav=True, peaked=True)),
 }

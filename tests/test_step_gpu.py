@@ -25,7 +25,7 @@ BF16_GRAD_RTOL = 8e-2
 GOLDEN_CASES = ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "7b_l2_all", "7b_l2_vqa", "7b_full_all",
                 "7b_l2_b8_vqa", "7b_l2_b8_all", "7b_l2_s650_all", "13b_l2_all",
                 "tiny_all_peaked", "7b_l2_b8_vqa_peaked", "7b_l2_b8_all_peaked", "7b_full_all_peaked",
-                "7b_l2_s650_all_peaked", "13b_l2_all_peaked"]
+                "7b_l2_s650_all_peaked", "13b_l2_all_peaked", "7b_full_b8_vqa_peaked", "7b_full_s650_vqa_peaked"]
 # against the reference's golden the bf16 build measures (profiles/r02_parity_vs_golden.log): losses <= 3.1e-4, sampled
 # logits <= 7.5e-3 of the logit range, gradients <= 2.0e-2; the bounds below leave about 2.5x
 BF16_TOL = dict(loss=5e-3, logits=2e-2, layer=3e-2, grad=5e-2)
@@ -61,7 +61,8 @@ def test_fp32_step_matches_reference_golden(case):
 BF16_MIN_DECIDED = {"small_all": 0.40, "7b_l2_all": 0.49, "7b_full_all": 0.20, "7b_l2_b8_vqa": 0.55, "7b_l2_b8_all": 0.48,
                     "7b_l2_s650_all": 0.47, "13b_l2_all": 0.49,
                     "7b_l2_b8_vqa_peaked": 0.95, "7b_l2_b8_all_peaked": 0.95, "7b_full_all_peaked": 0.95,
-                    "7b_l2_s650_all_peaked": 0.95, "13b_l2_all_peaked": 0.95}
+                    "7b_l2_s650_all_peaked": 0.95, "13b_l2_all_peaked": 0.95,
+                    "7b_full_b8_vqa_peaked": 0.95, "7b_full_s650_vqa_peaked": 0.95}
 
 
 @pytest.mark.parametrize("case", list(BF16_MIN_DECIDED))
@@ -70,7 +71,8 @@ def test_bf16_step_against_reference_golden(case):
     shapes: losses within 5e-3, sampled logits within 2e-2 of the logit range, gradients within 5e-2 (max-abs over
     max-abs / norms; bf16 keeps 8 mantissa bits and the frozen weights themselves are rounded), and the token argmax
     equal on every row whose reference top-2 margin exceeds 8 x the measured logit error — at least BF16_MIN_DECIDED of
-    the rows: >= 95 % on the peaked fixtures at C2's, C3's, C4's (S = 650) and C5's (13B width) shapes and at full depth."""
+    the rows: >= 95 % on the peaked fixtures at C2's, C3's, C4's (S = 650) and C5's (13B width) shapes and at full depth
+    (incl. the benchmarked C2 workload itself, 32 layers at B = 8, and S = 650 at 32 layers)."""
     pname, over = CASES[case]
     cfg = synth.preset(pname, **over)
     model, _ = build_model(cfg, torch.bfloat16)

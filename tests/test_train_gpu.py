@@ -69,6 +69,36 @@ def test_one_optimizer_step_matches_oracle_plus_torch_adamw():
     assert scaler.state_dict()["scale"] == 65536.0
 
 
+def test_gradient_accumulation_matches_the_oracle():
+    """accum_iter = 2 as engine.train_one_epoch / the reference drive it (engine.py:37-41: loss / accum_iter, backward every
+    micro-batch, unscale + step only at the boundary): the gradient the optimizer sees is the MEAN of the two micro-batch
+    gradients — elementwise against the fp64 oracle — and the returned norm is its norm (util/misc.py:266-276)."""
+    cfg, model, args, opt = _setup()
+    b0, b1 = synth.make_batch(cfg, seed=11), synth.make_batch(cfg, seed=12)
+    scaler = misc.NativeScalerWithGradNormCount()
+    opt.zero_grad()
+    norm = None
+    for i, batch in enumerate((b0, b1)):
+        a, b, c = model(batch)
+        norm = scaler((a + b + c) / 2, opt, parameters=model.parameters(), update_grad=(i == 1))
+    torch.cuda.synchronize()
+    sd = synth.state_dict(cfg)
+    r0 = ref_cpu.RefModel(cfg, sd, dtype=torch.float64).step(b0)
+    r1 = ref_cpu.RefModel(cfg, sd, dtype=torch.float64).step(b1)
+    want = {n: (r0["grads"][n] + r1["grads"][n]) / 2 for n in r0["grads"]}
+    own = {n: p for n, p in model.named_parameters() if p.requires_grad}
+    assert set(own) == set(want)
+    for n, p in own.items():
+        got = p.grad.detach().double().cpu()
+        ref = want[n].reshape(got.shape)
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4, n
+        # and it is NOT one micro-batch's gradient (the fixture can tell them apart)
+        assert float((got - r1["grads"][n].reshape(got.shape)).abs().max() / ref.abs().max()) > 1e-2, n
+    ref_norm = torch.sqrt(sum(g.pow(2).sum() for g in want.values()))
+    assert abs(float(norm) - float(ref_norm)) / float(ref_norm) < 1e-4
+    assert opt.step_dev.item() == 1.0
+
+
 def test_train_one_epoch_contract_and_learning():
     cfg, model, args, opt = _setup(torch.bfloat16)
     args.accum_iter, args.lr, args.warmup_epochs, args.epochs = 2, 0.02, 0, 2

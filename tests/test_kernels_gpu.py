@@ -356,7 +356,19 @@ def _attn_case(dtype, N, S, H, A, F, vstart, seed=0):
 @pytest.mark.parametrize("N,S,H,vstart", [(2, 32, 2, [5, -1]), (3, 128, 2, [19, 19, -1]), (1, 200, 1, [19]),
                                           (2, 70, 3, [-1, 8]), (1, 650, 1, [19]), (2, 129, 1, [100, -1])])
 def test_attention_fwd_bwd(dtype, N, S, H, vstart):
-    A, F = 10, 10
+    _attention_fwd_bwd(dtype, N, S, H, vstart, 10, 10)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,S,H,vstart,A,F", [(2, 128, 2, [19, -1], 16, 6), (2, 128, 1, [40, 3], 1, 10),
+                                              (1, 200, 2, [7], 3, 16), (2, 64, 1, [0, 60], 16, 4)])
+def test_attention_other_adapter_lengths_and_frame_counts(dtype, N, S, H, vstart, A, F):
+    """--adapter_len / --max_feats other than the reference's default 10 / 10 (train.py:34,36): the whole 16-key adapter
+    block, a single adapter key, a frame window that starts at position 0 or runs into the end of the sequence."""
+    _attention_fwd_bwd(dtype, N, S, H, vstart, A, F)
+
+
+def _attention_fwd_bwd(dtype, N, S, H, vstart, A, F):
     qkv, g1, g2, vs, Dh, D = _attn_case(dtype, N, S, H, A, F, vstart, seed=S)
     d_o = rnd(N * S, D, dtype=dtype, seed=77)
     q = qkv[: N * S, :D].double().view(N, S, H, Dh)
@@ -387,11 +399,15 @@ def test_attention_fwd_bwd(dtype, N, S, H, vstart):
     assert rel(got[: N * S, :D], dq.reshape(N * S, D)) < t
     assert rel(got[: N * S, D:2 * D], dk.reshape(N * S, D)) < t
     assert rel(got[: N * S, 2 * D:], dv.reshape(N * S, D)) < t
-    assert rel(got[N * S:, D:2 * D], dak.reshape(A, D)) < t
+    if A == 1:        # a one-key softmax is constant: the oracle's dK_a is exactly 0, the kernel's is rounding noise
+        assert float(got[N * S:, D:2 * D].abs().max()) < 1e-5 * float(dk.abs().max())
+    else:
+        assert rel(got[N * S:, D:2 * D], dak.reshape(A, D)) < t
     assert rel(got[N * S:, 2 * D:], dav.reshape(A, D)) < t
     assert float(got[N * S:, :D].abs().max()) == 0.0
-    assert rel(dg1d - 1.0, dg1) < max(t, 1e-4)
-    assert rel(dg2d - 1.0, dg2) < max(t, 1e-4)
+    tg = tol(dtype, 1e-4, 3e-2)      # one scalar per head, summed from bf16-rounded products over few (frame) columns
+    assert rel(dg1d - 1.0, dg1) < tg
+    assert rel(dg2d - 1.0, dg2) < tg
 
 
 @pytest.mark.parametrize("N,S,H,vstart", [(2, 128, 2, [19, -1]), (1, 300, 1, [19]), (2, 70, 3, [-1, 8])])

@@ -116,6 +116,31 @@ def test_bf16_step_close_to_oracle(pname, over):
         assert err < 3e-2, (t, err)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("over", [dict(adapter_len=16, max_feats=6), dict(adapter_len=3, max_feats=16, max_seq_len=64)])
+def test_step_with_other_adapter_length_and_frame_count(dtype, over):
+    """--adapter_len / --max_feats away from the default 10 / 10: the whole step (three losses, every trainable's gradient)
+    against the oracle."""
+    cfg = synth.preset("tiny", vaq=True, qav=True, **over)
+    model, _ = build_model(cfg, dtype)
+    batch = synth.make_batch(cfg, seed=3)
+    losses, grads, _, _ = run_step(model, batch)
+    sd = synth.state_dict(cfg)
+    if dtype == torch.bfloat16:
+        for n in sd:
+            if not synth.is_trainable(n):
+                sd[n] = sd[n].to(torch.bfloat16).float()
+    ref = _oracle(cfg, sd, batch)
+    lt, gt = (1e-5, 2e-4) if dtype == torch.float32 else (BF16_LOSS_RTOL, BF16_GRAD_RTOL)
+    for t in ref["tasks"]:
+        r = float(ref["losses"][t])
+        assert abs(losses[t] - r) / abs(r) < lt, (t, losses[t], r)
+    for n, g in ref["grads"].items():
+        gn = float(g.norm())
+        if gn:
+            assert float((grads[n].double() - g).norm()) / gn < gt, n
+
+
 def test_bf16_full_7b_close_to_fp32_build():
     """The production (bf16) build at FULL size — 32-layer 7B, BASELINE configs[0]: B=2, S=128, three losses —
     against the fp32 build (itself pinned to the reference's golden for this very configuration) fed the same

@@ -117,10 +117,11 @@ def test_bf16_step_close_to_oracle(pname, over):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("over", [dict(adapter_len=16, max_feats=6), dict(adapter_len=3, max_feats=16, max_seq_len=64)])
+@pytest.mark.parametrize("over", [dict(adapter_len=16, max_feats=6), dict(adapter_len=3, max_feats=16, max_seq_len=64),
+                                  dict(bias=3.0, tau=50.0)])
 def test_step_with_other_adapter_length_and_frame_count(dtype, over):
-    """--adapter_len / --max_feats away from the default 10 / 10: the whole step (three losses, every trainable's gradient)
-    against the oracle."""
+    """--adapter_len / --max_feats away from the default 10 / 10, --bias 3 (the reference's STAR / DramaQA / VLEP / TVQA
+    scripts) and another --tau: the whole step (three losses, every trainable's gradient) against the oracle."""
     cfg = synth.preset("tiny", vaq=True, qav=True, **over)
     model, _ = build_model(cfg, dtype)
     batch = synth.make_batch(cfg, seed=3)

@@ -144,12 +144,15 @@ def test_step_with_other_adapter_length_and_frame_count(dtype, over):
             assert float((grads[n].double() - g).norm()) / gn < gt, n
 
 
-def test_bf16_full_7b_close_to_fp32_build():
-    """The production (bf16) build at FULL size — 32-layer 7B, BASELINE configs[0]: B=2, S=128, three losses —
-    against the fp32 build (itself pinned to the reference's golden for this very configuration) fed the same
-    bf16-rounded frozen weights. Same tolerances as the small bf16-vs-oracle cases."""
+@pytest.mark.parametrize("pname,over", [("7b", dict(batch_size=2, vaq=True, qav=True)),
+                                        ("13b", dict(batch_size=4, vaq=True, qav=True))])
+def test_bf16_full_size_close_to_fp32_build(pname, over):
+    """The production (bf16) build at FULL size — 32-layer 7B (BASELINE configs[0]: B=2, S=128, three losses) and 40-layer 13B
+    (configs[4]: B=4; the fp32 reference of that one does not fit the build container, so there is no golden at this depth)
+    — against the fp32 build (pinned to the reference's goldens at these widths) fed the same bf16-rounded frozen weights.
+    Same tolerances as the small bf16-vs-oracle cases."""
     import gc
-    cfg = synth.preset("7b", batch_size=2, vaq=True, qav=True)
+    cfg = synth.preset(pname, **over)
     batch = synth.make_batch(cfg, seed=0)
     model, _ = build_model(cfg, torch.float32)
     for n, p in model.named_parameters():
@@ -171,7 +174,7 @@ def test_bf16_full_7b_close_to_fp32_build():
         err = float((g16[n].double() - g.double()).norm()) / gn
         worst = max(worst, err)
         assert err < BF16_GRAD_RTOL, (n, err)
-    print("7B bf16 vs fp32 build: losses", l16, l32, "worst grad rel-L2", worst)
+    print(pname, "bf16 vs fp32 build: losses", l16, l32, "worst grad rel-L2", worst)
     del model
     gc.collect()
     torch.cuda.empty_cache()

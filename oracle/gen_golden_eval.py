@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE — generates tests/golden/eval_tiny.npz by running the REFERENCE's generation/eval path
+"""TEST INFRASTRUCTURE — generates tests/golden/eval_tiny.npz (and, run as `gen_golden_eval.py 7b_l2`, eval_7b_l2.npz) by running the REFERENCE's generation/eval path
 (llama/model.py:367-546 `Transformer.inference`) in this container: fp32-shim reference model with closed-form
 weights (as oracle/gen_golden.py), validation batches built by the reference's own NExT-QA reader + prompt
 templates on the synthetic table of oracle/gen_golden_loader.py (regex stand-in vocabulary, oracle/fake_sp.py).
@@ -53,8 +53,10 @@ def main():
     ds = D.NextQA(args=largs, tokenizer=tok, split="val")
     batch = D.batch_collate([ds[i] for i in range(4)])
 
-    # the reference model (tiny width, full vocabulary so that the prompt ids are valid)
-    cfg = synth.preset("tiny", vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4)
+    # the reference model (tiny width — or, with argument "7b_l2", 7B width two layers deep —, full vocabulary so that the
+    # prompt ids are valid)
+    pname = sys.argv[1] if len(sys.argv) > 1 else "tiny"
+    cfg = synth.preset(pname, vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4)
     model, margs = G.build_reference(M, cfg)
     margs.is_generation_task = True
     model.eval()
@@ -87,7 +89,7 @@ def main():
            "vstart_vqa": np.array(batch["video_start"]["vqa"], dtype=np.int64),
            "answer": batch["answer"].numpy(), "video": batch["video"].numpy(),
            "qtype": batch["qtype"].numpy()}
-    path = os.path.join(ROOT, "tests", "golden", "eval_tiny.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"eval_{pname}.npz")
     np.savez_compressed(path, **out)
     print("best", out["best"], "answers", out["answer"], "->", path, os.path.getsize(path) // 1024, "KiB")
     print("generated (first sample):", out["ids_after"][0, out["prefix_vqa"][0] - 2: out["prefix_vqa"][0] + 8])

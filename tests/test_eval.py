@@ -12,10 +12,11 @@ import torch
 import engine
 from util import misc
 
-GOLD = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_tiny.npz")))
+GOLDS = {p: dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"eval_{p}.npz"))) for p in ("tiny", "7b_l2")}
+GOLD = GOLDS["tiny"]
 
 
-def golden_batch():
+def golden_batch(GOLD=GOLD):
     B = GOLD["answer"].shape[0]
     return {"video": torch.from_numpy(GOLD["video"]), "text_id": {"vqa": torch.from_numpy(GOLD["text_id_vqa"])},
             "label": {"vqa": torch.from_numpy(GOLD["label_vqa"])},
@@ -25,17 +26,20 @@ def golden_batch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pname", ["tiny", "7b_l2"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_generation_matches_reference(dtype):
+def test_generation_matches_reference(dtype, pname):
     """fp32 build: the 31 greedy tokens per sample, the chosen option and the similarities equal the reference's
-    (argmax over fp32 logits that agree to ~1e-6). bf16 build: same code path, checked for shape / determinism and
-    that the prompt part is untouched (token-exactness against an fp32 reference is not defined for bf16)."""
+    (argmax over fp32 logits that agree to ~1e-6) — at tiny width and at 7B width (32 heads, D = 4096, two layers). bf16
+    build: same code path, checked for shape / determinism and that the prompt part is untouched (token-exactness against an
+    fp32 reference is not defined for bf16)."""
     from fvqa import synth
     from tests.gpu_util import build_model
-    cfg = synth.preset("tiny", vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4)
+    GOLD = GOLDS[pname]
+    cfg = synth.preset(pname, vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4)
     model, _ = build_model(cfg, dtype)
     model.eval()
-    batch = golden_batch()
+    batch = golden_batch(GOLD)
     best, extracted = model(batch, inference=True)
     ids = model.last_generation["ids"].cpu().numpy()
     assert ids.shape == GOLD["ids_after"].shape and len(extracted) == ids.shape[0]

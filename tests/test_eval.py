@@ -60,6 +60,24 @@ def test_generation_matches_reference(dtype, pname):
     assert torch.isfinite(loss)
 
 
+@pytest.mark.gpu
+def test_val_one_epoch_with_the_model_reports_the_references_accuracy(tmp_path):
+    """engine.val_one_epoch driving the real model (fp32 build, 7B width) over the reference's validation batch: accuracy and
+    per-type meters are those of the reference's own choices (fixture), the answers file is written per batch."""
+    from fvqa import synth
+    from tests.gpu_util import build_model
+    G = GOLDS["7b_l2"]
+    cfg = synth.preset("7b_l2", vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4)
+    model, _ = build_model(cfg, torch.float32)
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.25}])
+    args = types.SimpleNamespace(is_generation_task=True, dataset="nextqa", debug=False, output_dir=str(tmp_path))
+    stats = engine.val_one_epoch(model, [golden_batch(G), golden_batch(G)], opt, epoch=1, args=args)
+    want = float((G["best"] == G["answer"]).mean())
+    assert stats["acc"] == pytest.approx(want) and stats["Total"] == pytest.approx(want) and stats["lr"] == 0.25
+    merged = json.load(open(tmp_path / "extracted_answers" / "extracted_answers_epoch1.json"))
+    assert [m["video_id"] for m in merged] == [f"v{i}" for i in range(G["answer"].shape[0])]
+
+
 def test_log_qtype_matches_reference_formulas():
     """C / T / D / Total meters as util/misc.py:443-449 of the reference computes them."""
     log = misc.MetricLogger()

@@ -46,6 +46,16 @@ def test_oracle_matches_reference_7b_width():
     compare_with_golden(g, res["losses"], res["grads"], res["extras"]["logits"], lo, rtol=2e-4)
 
 
+@pytest.mark.parametrize("case", ["7b_l2_b8_vqa_peaked", "7b_l2_s256_b4_all_peaked"])
+def test_oracle_matches_reference_at_benchmark_shapes(case):
+    """C2's shape (B = 8, S = 128, VQA loss) and a longer three-loss shape (S = 256, B = 4), 7B width, two layers, peaked
+    logits: every token argmax of the oracle equals the reference's (fp32 to bound memory / time)."""
+    g = load_golden(case)
+    res, lo = run_oracle(case, torch.float32)
+    rep = compare_with_golden(g, res["losses"], res["grads"], res["extras"]["logits"], lo, rtol=2e-4, min_decided=0.99)
+    assert rep["argmax_vqa_decided"].split("/")[0] == rep["argmax_vqa_decided"].split("/")[1]
+
+
 def test_oracle_backward_matches_autograd():
     """The hand-derived attention backward against autograd of the same forward."""
     torch.manual_seed(0)

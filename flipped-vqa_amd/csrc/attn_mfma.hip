@@ -43,8 +43,21 @@ constexpr float NEG_BIG = -1e30f;
 #ifdef FVQA_ATTN_STAMPS
 __device__ unsigned long long g_attn_stamps[1024 * 16];
 #define AT_STAMP(slot) do { if (threadIdx.x == 0) g_attn_stamps[(size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 1023) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// forward kernel: per workgroup, thread 0 (wave 0) and thread 448 (wave 7) sum the time they spend in each phase of the key-tile
+// loop (slots 0-7 / 8-15: start, commit, barrier after commit, key groups, barrier before commit, end, tiles walked, query block)
+#define AT_NOW() __builtin_amdgcn_s_memrealtime()
+#define AT_FWD_DECL unsigned long long at_t = 0, at_commit = 0, at_bar2 = 0, at_groups = 0, at_bar1 = 0, at_start = 0; \
+  const bool at_me = threadIdx.x == 0 || threadIdx.x == 448; if (at_me) { at_start = AT_NOW(); at_t = at_start; }
+#define AT_FWD_ADD(acc) do { if (at_me) { const unsigned long long n_ = AT_NOW(); acc += n_ - at_t; at_t = n_; } } while (0)
+#define AT_FWD_DUMP(tiles, qb_) do { if (at_me) { unsigned long long* p_ = g_attn_stamps + \
+    (size_t)(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 1023) * 16 + (threadIdx.x == 0 ? 0 : 8); \
+    p_[0] = at_start; p_[1] = at_commit; p_[2] = at_bar2; p_[3] = at_groups; p_[4] = at_bar1; p_[5] = AT_NOW(); \
+    p_[6] = (tiles); p_[7] = (qb_); } } while (0)
 #else
 #define AT_STAMP(slot) do { } while (0)
+#define AT_FWD_DECL
+#define AT_FWD_ADD(acc) do { } while (0)
+#define AT_FWD_DUMP(tiles, qb_) do { } while (0)
 #endif
 
 // D[4g+r][lane&15] += sum_k X[4g+r][k] * Y[lane&15][k]
@@ -241,16 +254,23 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
   const int vs = vstart[n];
   const float g2 = gate2[h];
   const bool biased_row = vs >= 0 && iq >= vs + F;
+  constexpr float LOG2E = 1.44269504089f;
+  const float sc2 = sc * LOG2E, g2l = g2 * LOG2E;        // scores in the log2 domain
+  const bool bias_any = vs >= 0 && i0 + 15 >= vs + F;     // some row of this wave takes the frame bias (wave-uniform)
 
+  AT_FWD_DECL
   for (int kt = 0; kt <= qb; ++kt) {
     if (kt > 0) __syncthreads();                          // tile kt-1 fully consumed
+    AT_FWD_ADD(at_bar1);
     tile_commit<ROPE, BQ>(rK, sK, kt * BQ, S, cs, sn);
     tile_commit<false, BQ>(rV, sV, kt * BQ, S, nullptr, nullptr);
     if (kt < qb) {                                        // next tile's loads fly under this tile's arithmetic
       tile_load<BQ>(rK, seq + D, ld, (kt + 1) * BQ, S);
       tile_load<BQ>(rV, seq + 2 * D, ld, (kt + 1) * BQ, S);
     }
+    AT_FWD_ADD(at_commit);
     __syncthreads();
+    AT_FWD_ADD(at_bar2);
     const int jlast = min(i0 + 15, S - 1) - kt * BQ;      // last tile-local key any row of this wave sees
     // (a wave whose 16 queries all lie beyond S — the ragged last block — only takes part in the staging)
     const int ng = (jlast < 0 || i0 >= S) ? 0 : min(4, (jlast >> 5) + 1);
@@ -263,47 +283,67 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
         st[0] = mma(kfr[0][ks], qf[ks], st[0]);
         st[1] = mma(kfr[1][ks], qf[ks], st[1]);
       }
+      // The key loop is bound by the vector ALU (softmax bookkeeping), not by the matrix pipe: scores are kept in the
+      // log2 domain (one FMA + one v_exp_f32 per element), and a group whose 32 keys lie below every query of the wave,
+      // inside the sequence and outside the frame-bias window takes no mask / bias instructions at all (wave-uniform test).
+      const int j0 = kt * BQ + 32 * gq;
+      const bool edge = j0 + 31 > i0 || j0 + 31 >= S || (bias_any && j0 < vs + F && j0 + 31 >= vs);
       float v[2][4], mx = NEG_BIG;
+      if (!edge) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = kt * BQ + 32 * gq + 16 * c + 4 * g + r;
-          float x = st[c][r] * sc;
-          if (biased_row && j >= vs && j < vs + F) x += g2;
-          x = (j <= iq && j < S) ? x : NEG_BIG;
-          v[c][r] = x;
-          mx = fmaxf(mx, x);
-        }
+          for (int r = 0; r < 4; ++r) {
+            v[c][r] = st[c][r] * sc2;
+            mx = fmaxf(mx, v[c][r]);
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 16 * c + 4 * g + r;
+            float x = st[c][r] * sc2;
+            if (biased_row && j >= vs && j < vs + F) x += g2l;
+            x = (j <= iq && j < S) ? x : NEG_BIG;
+            v[c][r] = x;
+            mx = fmaxf(mx, x);
+          }
+      }
       mx = across_g_max(mx);
       TrRegs tv;
       tr_issue<true>(sV, 32 * gq, lane, tv);              // V fragments return under the exponentials
       const float mn = fmaxf(m, mx);
-      const float alpha = __expf(m - mn);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
       m = mn;
       float p[2][4], rs = 0.f;
+      const float mnc = mn > 0.5f * NEG_BIG ? mn : 0.f;   // a row with no key yet: every v is NEG_BIG, exp2 gives 0
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[c][r] = (v[c][r] > 0.5f * NEG_BIG) ? __expf(v[c][r] - mn) : 0.f;
+          p[c][r] = __builtin_amdgcn_exp2f(v[c][r] - mnc);
           rs += p[c][r];
         }
       ls = ls * alpha + rs;
+      if (__any(alpha != 1.f)) {                          // the running maximum moved for some row of this wave
 #pragma unroll
-      for (int d = 0; d < 8; ++d)
+        for (int d = 0; d < 8; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
+          for (int r = 0; r < 4; ++r) oacc[d][r] *= alpha;
+      }
       const uint4 pf = pack_blocks(p[0], p[1]);
       uint4 vf[8];
       tr_collect<true>(tv, vf);
 #pragma unroll
       for (int d = 0; d < 8; ++d) oacc[d] = mma(vf[d], pf, oacc[d]);
     }
+    AT_FWD_ADD(at_groups);
   }
+  AT_FWD_DUMP(qb + 1, qb);
   const float l = across_g_sum(ls);
   const float inv = 1.f / l;
-  const float lt = m + __logf(l);
+  const float lt = m * 0.69314718056f + __logf(l);        // m is a base-2 exponent
 #pragma unroll
   for (int d = 0; d < 8; ++d)
 #pragma unroll

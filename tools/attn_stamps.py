@@ -33,6 +33,42 @@ dg1, dg2 = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
 ws = torch.zeros(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=dev)
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.lib_path())
+if os.environ.get("AB_FWD"):
+    # forward kernel at S = AB_S (default 650), n_seq = AB_N (default 3): per workgroup, time of wave 0 / wave 7 per phase
+    S = int(os.environ.get("AB_S", "650"))
+    N = int(os.environ.get("AB_N", "3"))
+    qkv = (torch.randn(N * S + A, 3 * D, device=dev) * 0.5).bfloat16()
+    vs = torch.full((N,), 19, dtype=torch.int32, device=dev)
+    ang = torch.outer(torch.arange(2 * S, device=dev, dtype=torch.float32),
+                      1.0 / (10000.0 ** (torch.arange(0, Dh, 2, device=dev).float() / Dh)))
+    rope = (ang.cos().contiguous(), ang.sin().contiguous())
+    o = torch.empty(N * S, D, dtype=torch.bfloat16, device=dev)
+    la = torch.empty(N * H * S, device=dev)
+    lt = torch.empty_like(la)
+    raw.fvqa_attn_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = np.zeros(1024 * 16, dtype=np.uint64)
+    for _ in range(5):
+        ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope)
+    torch.cuda.synchronize()
+    raw.fvqa_attn_stamps_read(buf.ctypes.data, 1)
+    ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope)
+    torch.cuda.synchronize()
+    raw.fvqa_attn_stamps_read(buf.ctypes.data, 0)
+    nqb = (S + 127) // 128
+    st = buf.reshape(1024, 16)[: min(1024, N * H * nqb)].astype(np.float64)
+    st = st[st[:, 0] > 0]
+    t0 = st[:, 0].min()
+    print(f"attn_fwd n_seq={N} S={S} H={H}: {len(st)} workgroups stamped; kernel span {(st[:, 5].max() - t0) / 100:.1f} us; "
+          f"last start {(st[:, 0].max() - t0) / 100:.1f} us")
+    for qb in range(nqb):
+        for off, wn in ((0, "wave 0"), (8, "wave 7")):
+            r = st[st[:, 7] == qb]
+            if not len(r):
+                continue
+            f = lambda c: np.median(r[:, off + c]) / 100.0
+            print(f"  query block {qb} ({qb + 1} tiles) {wn}: life {np.median(r[:, off + 5] - r[:, off + 0]) / 100:6.1f} us = "
+                  f"commit {f(1):5.1f} + barrier {f(2):5.1f} + key groups {f(3):5.1f} + barrier {f(4):5.1f} + rest")
+    sys.exit(0)
 raw.fvqa_attn_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = np.zeros(1024 * 16, dtype=np.uint64)
 ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope)

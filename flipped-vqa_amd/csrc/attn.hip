@@ -482,7 +482,7 @@ int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const fl
                        const float* gate1, const float* gate2, const int32_t* vstart, const float* cos_t,
                        const float* sin_t, void* dqkv, float* dgate1, float* dgate2, float* delta_a, float* delta_t,
                        float* gate_part, float* dka, float* dva, int* arrive, int n_seq, int S, int H, int A, int F,
-                       hipStream_t st);
+                       hipStream_t st, int prerotated);
 static bool use_mfma_attention() {
   static const bool v = [] { const char* e = getenv("FVQA_ATTN_VALU"); return !(e && e[0] == '1'); }();
   return v;
@@ -525,12 +525,13 @@ extern "C" size_t fvqa_attn_bwd_workspace(int n_seq, int seq_len, int n_heads, i
   return bwd_ws(n_seq, seq_len, n_heads, adapter_len).total;
 }
 
-extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, const float* lse_a,
+static int attn_bwd_impl(const void* d_o, const void* qkv, const void* o, const float* lse_a,
                              const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
                              const float* cos_t, const float* sin_t, void* dqkv, float* dgate1, float* dgate2,
                              void* workspace, size_t workspace_bytes, int n_seq, int seq_len, int n_heads,
-                             int head_dim, int adapter_len, int max_feats, int dtype, void* stream) {
+                             int head_dim, int adapter_len, int max_feats, int dtype, void* stream, int prerotated) {
   if ((cos_t == nullptr) != (sin_t == nullptr)) return FVQA_EINVAL;
+  if (prerotated && !cos_t) return FVQA_EINVAL;
   if (cos_t && !fvqa_attn_rope_fused(dtype)) return FVQA_EINVAL;
   if (!d_o || !qkv || !o || !lse_a || !lse_t || !gate1 || !gate2 || !vstart || !dqkv || !dgate1 || !dgate2 ||
       !workspace)
@@ -554,7 +555,7 @@ extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, co
   if (dtype == FVQA_BF16 && use_mfma_attention()) {
     const int reduced = fvqa_attn_bwd_mfma(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, dqkv, dgate1,
                                            dgate2, delta_a, delta_t, gate_part, dka, dva, (int*)(wb + ws.arrive), n_seq,
-                                           seq_len, n_heads, adapter_len, max_feats, st);
+                                           seq_len, n_heads, adapter_len, max_feats, st, prerotated);
     if (!reduced)
       hipLaunchKernelGGL(attn_bwd_reduce_k<bf16_t>, dim3(64), block, 0, st, dka, dva, gate_part, gate1, (bf16_t*)dqkv,
                          dgate1, dgate2, n_seq, seq_len, n_heads, adapter_len, fvqa_attn_mfma_qblocks(seq_len));
@@ -584,4 +585,24 @@ extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, co
   }
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
+}
+
+extern "C" int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, const float* lse_a,
+                             const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
+                             const float* cos_t, const float* sin_t, void* dqkv, float* dgate1, float* dgate2,
+                             void* workspace, size_t workspace_bytes, int n_seq, int seq_len, int n_heads,
+                             int head_dim, int adapter_len, int max_feats, int dtype, void* stream) {
+  return attn_bwd_impl(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, dqkv, dgate1, dgate2, workspace,
+                       workspace_bytes, n_seq, seq_len, n_heads, head_dim, adapter_len, max_feats, dtype, stream, 0);
+}
+
+// q, k in `qkv` ALREADY ROTATED (fvqa_gemm_nt_rope); dqkv receives the gradients of the RAW projections (bf16 MFMA build)
+extern "C" int fvqa_attn_bwd_rotated(const void* d_o, const void* qkv, const void* o, const float* lse_a,
+                                     const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
+                                     const float* cos_t, const float* sin_t, void* dqkv, float* dgate1, float* dgate2,
+                                     void* workspace, size_t workspace_bytes, int n_seq, int seq_len, int n_heads,
+                                     int head_dim, int adapter_len, int max_feats, int dtype, void* stream) {
+  if (!cos_t || !sin_t || !fvqa_attn_rope_fused(dtype)) return FVQA_EINVAL;
+  return attn_bwd_impl(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, dqkv, dgate1, dgate2, workspace,
+                       workspace_bytes, n_seq, seq_len, n_heads, head_dim, adapter_len, max_feats, dtype, stream, 1);
 }

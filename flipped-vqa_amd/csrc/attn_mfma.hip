@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_k(const bf16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------- backward: dQ
-template <bool ROPE>
+template <bool ROPE, bool RIN = ROPE>   // ROPE: conjugate rotation of dq / dk at the store; RIN: q, k arrive raw and are rotated on load
 __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
     const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
     const float* __restrict__ lse_a, const float* __restrict__ lse_t, const float* __restrict__ gate1,
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   float dtot = 0.f;                                       // dO·O over the row: this lane's 32 dims, then across g
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    if (ROPE) qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
+    if (RIN) qf[ks] = rope8(qf[ks], cs + (size_t)iqc * HP + 16 * ks + 4 * g, sn + (size_t)iqc * HP + 16 * ks + 4 * g);
     const uint4 of = off[ks];
     const unsigned tw[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w}, uw[4] = {of.x, of.y, of.z, of.w};
 #pragma unroll
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   // ---- adapter block: dS_a, delta_a, d tanh-gate partial
   tile_commit<false, 16>(rKa, sKa, 0, A, nullptr, nullptr);
   tile_commit<false, 16>(rVa, sVa, 0, A, nullptr, nullptr);
-  tile_commit<ROPE, BQ>(rK, sK, 0, S, cs, sn);
+  tile_commit<RIN, BQ>(rK, sK, 0, S, cs, sn);
   tile_commit<false, BQ>(rV, sV, 0, S, nullptr, nullptr);
   __syncthreads();
   float da, dg1 = 0.f, dg2 = 0.f;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   for (int kt = 0; kt <= qb; ++kt) {
     if (kt > 0) {
       __syncthreads();                                    // tile kt-1 fully consumed
-      tile_commit<ROPE, BQ>(rK, sK, kt * BQ, S, cs, sn);
+      tile_commit<RIN, BQ>(rK, sK, kt * BQ, S, cs, sn);
       tile_commit<false, BQ>(rV, sV, kt * BQ, S, nullptr, nullptr);
       if (kt < qb) {
         tile_load<BQ>(rK, seq + D, ld, (kt + 1) * BQ, S);
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
 // ------------------------------------------------------------------------------- backward: dK, dV
 // kb < nkb: 128 text keys (16 per wave); kb == nkb: the adapter keys (one 16-key block;
 // waves 0-3 take the 32-query groups g ≡ w of every query tile and their partial sums meet in LDS).
-template <bool ROPE>
+template <bool ROPE, bool RIN = ROPE>   // ROPE: conjugate rotation of dq / dk at the store; RIN: q, k arrive raw and are rotated on load
 __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
     const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv, const float* __restrict__ lse_a,
     const float* __restrict__ lse_t, const float* __restrict__ delta_a, const float* __restrict__ delta_t,
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   }
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    if (ROPE && !adapter)
+    if (RIN && !adapter)
       kf[ks] = rope8(kf[ks], cs + (size_t)jc * HP + 16 * ks + 4 * g, sn + (size_t)jc * HP + 16 * ks + 4 * g);
     if (!kok) { kf[ks] = make_uint4(0, 0, 0, 0); vf[ks] = make_uint4(0, 0, 0, 0); }
   }
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   const bool win_key = vs >= 0 && jk >= vs && jk < vs + F;
   for (int t = t_first; t < nqt; ++t) {
     if (t > t_first) __syncthreads();                     // tile t-1 fully consumed
-    tile_commit<ROPE, BQ>(rQ, sQ, t * BQ, S, cs, sn);
+    tile_commit<RIN, BQ>(rQ, sQ, t * BQ, S, cs, sn);
     tile_commit<false, BQ>(rdO, sdO, t * BQ, S, nullptr, nullptr);
     if (threadIdx.x < BQ) {
       sL[threadIdx.x] = l_in;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
 // The batch reduction of the adapter partials and of the gate sums is done by the LAST workgroup of each head to
 // arrive (integer arrival counter in the workspace, self-resetting; partials are summed in sequence order, so the
 // result does not depend on which workgroup is last): no separate reduction launch.
-template <bool ROPE>
+template <bool ROPE, bool RIN = ROPE>   // ROPE: conjugate rotation of dq / dk at the store; RIN: q, k arrive raw and are rotated on load
 __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
     const float* __restrict__ lse_a, const float* __restrict__ lse_t, const float* __restrict__ gate1,
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
       lt_in = lse_t[sbase + ii];
       la_in = lse_a[sbase + ii];
     }
-    tile_commit<ROPE, BQ>(rQ, sQ, 0, S, cs, sn);
-    tile_commit<ROPE, BQ>(rK, sK, 0, S, cs, sn);
+    tile_commit<RIN, BQ>(rQ, sQ, 0, S, cs, sn);
+    tile_commit<RIN, BQ>(rK, sK, 0, S, cs, sn);
     tile_commit<false, BQ>(rV, sV, 0, S, nullptr, nullptr);
     tile_commit<false, BQ>(rdO, sdO, 0, S, nullptr, nullptr);
     tile_commit<false, 16>(rKa, sKa, 0, A, nullptr, nullptr);
@@ -1200,10 +1200,15 @@ int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const fl
                        const float* gate1, const float* gate2, const int32_t* vstart, const float* cos_t,
                        const float* sin_t, void* dqkv, float* dgate1, float* dgate2, float* delta_a, float* delta_t,
                        float* gate_part, float* dka, float* dva, int* arrive, int n_seq, int S, int H, int A, int F,
-                       hipStream_t st) {
+                       hipStream_t st, int prerotated) {
+  // prerotated (with tables): q, k in `qkv` are already rotated (fvqa_gemm_nt_rope), dq / dk are conjugate-rotated at the
+  // store so that dqkv holds the gradients of the RAW projections
   const int nqb = fvqa_attn_mfma_qblocks(S);
   static bool attr = false;
   if (!attr) {
+    allow_lds((attn_bwd_dq_mfma_k<true, false>), FWD_LDS);
+    allow_lds((attn_bwd_dkv_mfma_k<true, false>), DKV_LDS);
+    allow_lds((attn_bwd_fused_k<true, false>), FUSED_LDS);
     allow_lds(attn_bwd_dq_mfma_k<true>, FWD_LDS);
     allow_lds(attn_bwd_dq_mfma_k<false>, FWD_LDS);
     allow_lds(attn_bwd_dkv_mfma_k<true>, DKV_LDS);
@@ -1213,23 +1218,25 @@ int fvqa_attn_bwd_mfma(const void* d_o, const void* qkv, const void* o, const fl
     attr = true;
   }
   static const bool no_fuse = [] { const char* e = getenv("FVQA_ATTN_BWD_SPLIT"); return e && e[0] == '1'; }();
+#define COMMA ,
   if (nqb == 1 && !no_fuse) {
 #define FVQA_FUSED(R)                                                                                                 \
-  hipLaunchKernelGGL(attn_bwd_fused_k<R>, dim3(H, n_seq), dim3(512), FUSED_LDS, st, (const bf16_t*)d_o,                \
+  hipLaunchKernelGGL((attn_bwd_fused_k<R>), dim3(H, n_seq), dim3(512), FUSED_LDS, st, (const bf16_t*)d_o,                \
                      (const bf16_t*)qkv, (const bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t,          \
                      (bf16_t*)dqkv, dgate1, dgate2, gate_part, dka, dva, arrive, n_seq, S, H, A, F);
-    if (cos_t) { FVQA_FUSED(true) } else { FVQA_FUSED(false) }
+    if (cos_t && prerotated) { FVQA_FUSED(true COMMA false) } else if (cos_t) { FVQA_FUSED(true) } else { FVQA_FUSED(false) }
 #undef FVQA_FUSED
     return 1;
   }
 #define FVQA_BWD(R)                                                                                                   \
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_k<R>, dim3(H, n_seq, nqb), dim3(512), FWD_LDS, st, (const bf16_t*)d_o,           \
+  hipLaunchKernelGGL((attn_bwd_dq_mfma_k<R>), dim3(H, n_seq, nqb), dim3(512), FWD_LDS, st, (const bf16_t*)d_o,           \
                      (const bf16_t*)qkv, (const bf16_t*)o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t,          \
                      (bf16_t*)dqkv, delta_a, delta_t, gate_part, n_seq, S, H, A, F);                                  \
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_k<R>, dim3(H, n_seq, nqb + 1), dim3(512), DKV_LDS, st, (const bf16_t*)d_o,      \
+  hipLaunchKernelGGL((attn_bwd_dkv_mfma_k<R>), dim3(H, n_seq, nqb + 1), dim3(512), DKV_LDS, st, (const bf16_t*)d_o,      \
                      (const bf16_t*)qkv, lse_a, lse_t, delta_a, delta_t, gate1, gate2, vstart, cos_t, sin_t,          \
                      (bf16_t*)dqkv, dka, dva, n_seq, S, H, A, F, nqb);
-  if (cos_t) { FVQA_BWD(true) } else { FVQA_BWD(false) }
+  if (cos_t && prerotated) { FVQA_BWD(true COMMA false) } else if (cos_t) { FVQA_BWD(true) } else { FVQA_BWD(false) }
 #undef FVQA_BWD
+#undef COMMA
   return 0;
 }

@@ -235,7 +235,7 @@ int launch_skinny(const void* A, const void* B, void* C, const void* R, int M, i
 extern "C" size_t fvqa_gemm_sk_workspace(void);
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
-                      const fvqa_sk_rider* rider, int* rode, void* C2 = nullptr);
+                      const fvqa_sk_rider* rider, int* rode, void* C2 = nullptr, const fvqa_sk_rope* rope = nullptr);
 
 extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
   (void)K; (void)dtype;
@@ -331,6 +331,44 @@ extern "C" int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const v
                         rider->ldb, rider->ldc, 0, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
   return fvqa_gemm_nt(rider->A, rider->B, rider->C, nullptr, nullptr, rider->M, rider->N, rider->K, rider->lda, rider->ldb,
                       rider->ldc, rider->M, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+}
+
+extern "C" int fvqa_rope_qk(void* qkv, const float* cos_t, const float* sin_t, int n_seq, int seq_len, int n_heads,
+                            int head_dim, int inverse, int dtype, void* stream);
+
+// The QKV projection with RoPE applied to its q | k columns in the epilogue (bf16): C[M, N] = A · B^T, columns [0, rope->cols)
+// rotated with the tables of position (row % seq_len). Shapes the persistent kernel does not take run the plain product and
+// the row kernel rope_qk_k after it — same arithmetic (value rounded to bf16, rotated in fp32, rounded again).
+extern "C" int fvqa_gemm_nt_rope(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                 const fvqa_sk_rope* rope, const fvqa_sk_rider* rider, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!A || !B || !C || !rope || !rope->cos_t || !rope->sin_t) return FVQA_EINVAL;
+  if (rope->seq_len <= 0 || rope->head_dim <= 0 || (rope->head_dim % 8) || rope->cols <= 0 || rope->cols > N ||
+      (rope->cols % (2 * rope->head_dim)) || M % rope->seq_len)
+    return FVQA_ESHAPE;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 64) || lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((size_t)lda * 2 & 15) || ((size_t)ldb * 2 & 15)) return FVQA_EALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  const bool sk_ok = (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)C & 15) == 0 && workspace != nullptr &&
+                     ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace() && M >= 192 && N >= 256;
+  int rode = 0, rc;
+  if (sk_ok) {
+    rc = fvqa_gemm_sk_impl(A, B, C, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, FVQA_BF16, FVQA_BF16,
+                           FVQA_EPI_ROPE, st, rider, &rode, nullptr, rope);
+  } else {
+    if (ldc != 3 * (rope->cols / 2)) return FVQA_ESHAPE;     // the row kernel takes fused q | k | v rows only
+    rc = fvqa_gemm_nt(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, M, FVQA_BF16, FVQA_BF16, FVQA_EPI_NONE, 0, workspace,
+                      workspace_bytes, stream);
+    if (!rc)
+      rc = fvqa_rope_qk(C, rope->cos_t, rope->sin_t, M / rope->seq_len, rope->seq_len, rope->cols / 2 / rope->head_dim,
+                        rope->head_dim, 0, FVQA_BF16, stream);
+  }
+  if (rc || rode || !rider) return rc;
+  if (rider->accumulate_f32)
+    return fvqa_gemm_nt(rider->A, rider->B, nullptr, nullptr, (float*)rider->C, rider->M, rider->N, rider->K, rider->lda,
+                        rider->ldb, rider->ldc, 0, FVQA_BF16, FVQA_BF16, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+  return fvqa_gemm_nt(rider->A, rider->B, rider->C, nullptr, nullptr, rider->M, rider->N, rider->K, rider->lda, rider->ldb,
+                      rider->ldc, rider->M, FVQA_BF16, FVQA_BF16, FVQA_EPI_NONE, 0, nullptr, 0, stream);
 }
 
 static int swiglu_fwd_impl(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K, int lda, int ldb,

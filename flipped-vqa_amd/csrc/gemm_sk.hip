@@ -57,6 +57,9 @@ struct SkArgs {
   u64 epoch;
   fvqa_sk_plan plan;
   SkRider rider;
+  // FVQA_EPI_ROPE (the QKV projection): columns [0, rope_cols) are q | k heads of 2*rope_hp dims, row m is position m % rope_S
+  const float* rope_cos; const float* rope_sin;
+  int rope_S, rope_cols, rope_hp;
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nwg) {     // consecutive work ids share an XCD (bijective)
@@ -205,6 +208,24 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[8][4], char* smem, const
         }
       } else {
         TO* cp = C + (size_t)m * ldc;
+        if constexpr (EPI == FVQA_EPI_ROPE && sizeof(TO) == 2) {
+          // RoPE of the q | k columns where they are produced (model.py:61-67 applied to wq(x), wk(x)): this lane holds 4
+          // rotation pairs of one row; the arithmetic of rope_qk_k / rope8 — value rounded to the storage type, rotated in
+          // fp32, rounded again — so the attention kernels read finished operands and no key tile is rotated twice
+          if (nA < a.rope_cols) {
+            const int pos = m % a.rope_S;
+            const size_t ti = (size_t)pos * a.rope_hp + ((nA % (2 * a.rope_hp)) >> 1);
+            const float4 c4 = *reinterpret_cast<const float4*>(a.rope_cos + ti);
+            const float4 s4 = *reinterpret_cast<const float4*>(a.rope_sin + ti);
+            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr) {
+              const float e = round_to<TO>(v[2 * pr]), d = round_to<TO>(v[2 * pr + 1]);
+              v[2 * pr] = e * cc[pr] - d * ss[pr];
+              v[2 * pr + 1] = e * ss[pr] + d * cc[pr];
+            }
+          }
+        }
         if constexpr (EPI == FVQA_EPI_RESIDUAL) {
           float r_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           if constexpr (sizeof(T) == 2) {
@@ -551,8 +572,12 @@ extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, i
 // and the caller launches it on its own.
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
-                      const fvqa_sk_rider* rider, int* rode, void* C2) {
+                      const fvqa_sk_rider* rider, int* rode, void* C2, const fvqa_sk_rope* rope) {
   if (rode) *rode = 0;
+  if ((epilogue == FVQA_EPI_ROPE) != (rope != nullptr)) return FVQA_EINVAL;
+  if (rope && (dtype != FVQA_BF16 || out_dtype != FVQA_BF16 || !rope->cos_t || !rope->sin_t || rope->seq_len <= 0 ||
+               rope->head_dim <= 0 || (rope->head_dim % 8) || rope->cols < 0 || rope->cols > N || (rope->cols % rope->head_dim)))
+    return FVQA_EINVAL;
   if (!ws || ws_bytes < fvqa_gemm_sk_workspace() || ((uintptr_t)ws & 255)) return FVQA_EALIGN;
   {
     // the launch epoch is a host-side kernel argument: a captured launch would be replayed with a stale epoch, its
@@ -572,6 +597,8 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   if (a.plan.n_teams * a.plan.ts > 256 || a.plan.n_teams * a.plan.ts > n_cu) return FVQA_ESHAPE;
   a.epoch = g_epoch.fetch_add(1) + 1;
   a.rider = SkRider{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
+  a.rope_cos = rope ? rope->cos_t : nullptr; a.rope_sin = rope ? rope->sin_t : nullptr;
+  a.rope_S = rope ? rope->seq_len : 1; a.rope_cols = rope ? rope->cols : 0; a.rope_hp = rope ? rope->head_dim / 2 : 1;
   const int idle = (n_cu < 256 ? n_cu : 256) - a.plan.n_teams * a.plan.ts;
   static const bool ride = !(getenv("FVQA_RIDER") && getenv("FVQA_RIDER")[0] == '0');   // tuning: FVQA_RIDER=0 keeps riders as own launches
   if (ride && rider && dtype == FVQA_BF16 && idle >= 16 && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 &&
@@ -589,6 +616,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     case FVQA_EPI_SWIGLU_FWD: return launch_sk<T, TO, FVQA_EPI_SWIGLU_FWD>(a, st);            \
     case FVQA_EPI_SWIGLU_BWD_ST: return launch_sk<T, TO, FVQA_EPI_SWIGLU_BWD_ST>(a, st);      \
     case FVQA_EPI_SWIGLU_FWD_ST: return launch_sk<T, TO, FVQA_EPI_SWIGLU_FWD_ST>(a, st);      \
+    case FVQA_EPI_ROPE: return launch_sk<T, TO, FVQA_EPI_ROPE>(a, st);                        \
     default: return FVQA_EINVAL;                                                              \
   }
   if (dtype == FVQA_BF16) {

@@ -38,6 +38,17 @@ bool swiglu_st() {
   return v;
 }
 
+}  // namespace
+
+// 1: the QKV projection rotates q and k in its epilogue (fvqa_gemm_nt_rope) and the attention kernels read finished operands
+// (bf16 MFMA build; FVQA_ROPE_IN_GEMM=0 keeps the round-2 form: raw q, k in the arena, rotated inside every attention kernel)
+extern "C" int fvqa_rope_in_gemm(int dtype) {
+  static const bool off = [] { const char* e = getenv("FVQA_ROPE_IN_GEMM"); return e && e[0] == '0'; }();
+  return fvqa_attn_rope_fused(dtype) != 0 && !off ? 1 : 0;
+}
+
+namespace {
+
 int check_plan_dims_only(const fvqa_layer_plan* p) {
   if (!p) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(p->dtype)) return FVQA_EINVAL;
@@ -92,6 +103,7 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
   const int R = n_seq * S, Ra = R + A;
   const size_t es = fvqa_dtype_size(dt);
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
+  const bool rope_gemm = fvqa_rope_in_gemm(dt) != 0;
   if (!p->adapter_c) return FVQA_EINVAL;
   // the adapter prompts of all walked layers in storage dtype (model.py:339 `.half()`), one launch
   RUN(fvqa_cast_rows(p->adapter, p->adapter_c, L * A, D, dt, stream));
@@ -109,15 +121,22 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     // is never read) on the CUs the QKV GEMM leaves idle
     const fvqa_sk_rider kv = {at(p->adapter_c, (size_t)i * A * D, es), at(p->wqkv[i], (size_t)D * D, es),
                               at(qkv, (size_t)R * 3 * D + D, es), A, 2 * D, D, D, D, 3 * D, 0};
+    if (rope_gemm) {                                   // bf16 MFMA build: q, k are rotated where the projection produces them
+      const fvqa_sk_rope rp = {p->cos_t, p->sin_t, S, Dh, 2 * D};
+      RUN(fvqa_gemm_nt_rope(p->xn, p->wqkv[i], qkv, R, 3 * D, D, D, D, 3 * D, &rp, &kv, p->gemm_ws, p->gemm_ws_bytes, stream));
+      RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, nullptr, nullptr, n_seq, S, H, Dh, A,
+                        p->max_feats, dt, stream));
+    } else {
     RUN(fvqa_gemm_nt_rider(p->xn, p->wqkv[i], qkv, nullptr, R, 3 * D, D, D, D, 3 * D, dt, dt, FVQA_EPI_NONE, &kv,
                            p->gemm_ws, p->gemm_ws_bytes, stream));
-    if (fused_rope) {                                  // bf16 MFMA build: q,k stay raw and are rotated inside
+    if (fused_rope) {                                  // (FVQA_ROPE_IN_GEMM=0) q,k stay raw and are rotated inside
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t, n_seq, S, H, Dh,
                         A, p->max_feats, dt, stream));
     } else {
       RUN(fvqa_rope_qk(qkv, p->cos_t, p->sin_t, n_seq, S, H, Dh, 0, dt, stream));
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, nullptr, nullptr, n_seq, S, H, Dh, A,
                         p->max_feats, dt, stream));
+    }
     }
     // h = x + o·Wo^T (model.py:185), hn = RMSNorm(h)·w
     RUN(fvqa_gemm_nt(o, p->wo[i], h, x, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
@@ -154,6 +173,7 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
   void* nxt = p->dnxt;
   void* t = p->dz;                                     // (R, D) scratch for the GEMM outputs that feed the norm backward
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
+  const bool rope_gemm = fvqa_rope_in_gemm(dt) != 0;
   const int epi_sw = swiglu_st() ? FVQA_EPI_SWIGLU_BWD_ST : FVQA_EPI_SWIGLU_BWD;
   RUN(fvqa_rmsnorm_bwd(dxnf, at(p->xs, (size_t)L * R * D, es), p->norm_w, p->rstdN, nullptr, cur, R, D, dt, stream));
   for (int i = L - 1; i >= 0; --i) {
@@ -179,7 +199,11 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     RUN(fvqa_rmsnorm_bwd(t, h, p->fn[i], p->rstd2 + (size_t)i * R, cur, p->dh, R, D, dt, stream));
     RUN(fvqa_gemm_nt(p->dh, p->wo_t[i], p->d_o, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
-    if (fused_rope) {
+    if (rope_gemm) {
+      RUN(fvqa_attn_bwd_rotated(p->d_o, qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t,
+                                p->dqkv, p->dgate1[i], p->dgate2[i], p->attn_ws, p->attn_ws_bytes, n_seq, S, H, Dh, A,
+                                p->max_feats, dt, stream));
+    } else if (fused_rope) {
       RUN(fvqa_attn_bwd(p->d_o, qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t, p->dqkv,
                         p->dgate1[i], p->dgate2[i], p->attn_ws, p->attn_ws_bytes, n_seq, S, H, Dh, A, p->max_feats, dt,
                         stream));

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST = 0, 1, 3, 6
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -35,10 +35,13 @@ SIGNATURES = {
     "fvqa_swiglu_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "fvqa_swiglu_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "fvqa_attn_rope_fused": (_i, [_i]),
+    "fvqa_rope_in_gemm": (_i, [_i]),
+    "fvqa_gemm_nt_rope": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "fvqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_attn_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "fvqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "fvqa_attn_bwd_rotated": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_visual_proj_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "fvqa_visual_proj_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "fvqa_embed_splice": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -64,6 +67,11 @@ class SkRider(C.Structure):
     """Mirror of `fvqa_sk_rider` (include/fvqa.h)."""
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("M", "N", "K", "lda", "ldb", "ldc", "accumulate_f32")]
+
+
+class SkRope(C.Structure):
+    """Mirror of `fvqa_sk_rope` (include/fvqa.h)."""
+    _fields_ = [("cos_t", C.c_void_p), ("sin_t", C.c_void_p)] + [(n, C.c_int32) for n in ("seq_len", "head_dim", "cols")]
 
 
 class LayerPlan(C.Structure):

@@ -40,7 +40,7 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
         ar = eng.arena(B, S)
         vstart = eng.saved["vstart"]
         D, H, Dh, Hf, A, F, L, V = eng.D, eng.H, eng.Dh, eng.Hf, eng.A, eng.F, eng.L, eng.V
-        fused = ops.attn_rope_fused(eng.dtype)
+        fused = ops.attn_rope_fused(eng.dtype) and not ops.rope_in_gemm(eng.dtype)   # the prefill left RAW keys in the cache
         ids = ids_all[:, 0].to(dev).clone()
         prefix = torch.as_tensor([int(p) for p in data["prefix_index"]["vqa"]], device=dev)
         pos = prefix - 1                                    # start_idx of the first iteration

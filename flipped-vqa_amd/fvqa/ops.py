@@ -351,6 +351,43 @@ def _attn_shapes(qkv, n_seq, S, H, Dh, A):
     return D
 
 
+def rope_in_gemm(dtype: torch.dtype) -> bool:
+    """True when the step rotates q, k in the QKV projection's epilogue (gemm_nt_rope): the arena's qkv rows hold ROTATED
+    q, k, attn_fwd runs without tables and the backward is attn_bwd(..., prerotated=True)."""
+    return bool(_lib.load().fvqa_rope_in_gemm(dt_code(dtype)))
+
+
+def gemm_nt_rope(a, b, out, rope, seq_len, head_dim, n_heads, *, rider_a=None, rider_b=None, rider_out=None):
+    """out (M, 3*D) = a @ b.T with RoPE applied to the q | k columns [0, 2*D) in the epilogue (bf16; position = row % seq_len);
+    optional rider (<= 16 rows) as gemm_nt_rider."""
+    _dev(a, b, out, rider_a, rider_b, rider_out, rows_strided=True)
+    _need(a.dtype == b.dtype == out.dtype == torch.bfloat16, "gemm_nt_rope: bf16")
+    for t in (a, b, out):
+        _need(t.dim() == 2 and t.stride(1) == 1, "gemm_nt_rope: 2-D tensors with unit inner stride")
+    M, K = a.shape
+    N = b.shape[0]
+    D = n_heads * head_dim
+    _need(b.shape[1] == K and tuple(out.shape) == (M, N) and N >= 2 * D and M % seq_len == 0, "gemm_nt_rope: shapes")
+    cos_t, sin_t = _rope_tables(rope, seq_len, head_dim, "gemm_nt_rope")
+    _need(cos_t is not None, "gemm_nt_rope: rope tables")
+    rp = _lib.SkRope(cos_t.data_ptr(), sin_t.data_ptr(), seq_len, head_dim, 2 * D)
+    rd = None
+    if rider_a is not None:
+        M2, K2 = rider_a.shape
+        N2 = rider_b.shape[0]
+        _need(rider_b.shape[1] == K2 and tuple(rider_out.shape) == (M2, N2) and M2 <= 16 and rider_out.dtype == a.dtype and
+              rider_a.stride(1) == rider_b.stride(1) == rider_out.stride(1) == 1, "gemm_nt_rope: rider")
+        rd = _lib.SkRider(rider_a.data_ptr(), rider_b.data_ptr(), rider_out.data_ptr(), M2, N2, K2, rider_a.stride(0),
+                          rider_b.stride(0), rider_out.stride(0), 0)
+    ws = gemm_workspace(a.device)
+    import ctypes
+    rc = _lib.load().fvqa_gemm_nt_rope(_ptr(a), _ptr(b), _ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                       ctypes.byref(rp), ctypes.byref(rd) if rd is not None else None, _ptr(ws), ws.numel(),
+                                       _stream())
+    _lib.check(rc, "fvqa_gemm_nt_rope")
+    return out
+
+
 def attn_rope_fused(dtype: torch.dtype) -> bool:
     """True when attn_fwd / attn_bwd of this dtype rotate q,k themselves (rope=(cos, sin) argument)."""
     return bool(_lib.load().fvqa_attn_rope_fused(dt_code(dtype)))
@@ -410,7 +447,7 @@ def attn_bwd_workspace(n_seq, S, H, Dh, A) -> int:
 
 
 def attn_bwd(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace,
-             n_seq, S, H, Dh, A, F, rope=None):
+             n_seq, S, H, Dh, A, F, rope=None, prerotated=False):
     """`workspace`: attn_bwd_workspace(...) bytes, ZEROED once when allocated (its head holds the fused
     kernel's arrival counters, which every call leaves at zero again)."""
     _dev(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgate2, workspace)
@@ -426,9 +463,12 @@ def attn_bwd(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgat
     _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "attn_bwd: vstart")
     wbytes = workspace.numel() * workspace.element_size()
     _need(wbytes >= attn_bwd_workspace(n_seq, S, H, Dh, A), "attn_bwd: workspace too small")
-    rc = _lib.load().fvqa_attn_bwd(_ptr(d_o), _ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1),
-                                   _ptr(gate2), _ptr(vstart), _ptr(cos_t), _ptr(sin_t), _ptr(dqkv), _ptr(dgate1),
-                                   _ptr(dgate2), _ptr(workspace), wbytes, n_seq, S, H, Dh, A, F, dt_code(qkv.dtype), _stream())
+    # prerotated: q, k in `qkv` were rotated by gemm_nt_rope; dqkv still receives the gradients of the raw projections
+    fn = _lib.load().fvqa_attn_bwd_rotated if prerotated else _lib.load().fvqa_attn_bwd
+    _need(not prerotated or cos_t is not None, "attn_bwd: prerotated needs the rope tables")
+    rc = fn(_ptr(d_o), _ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1), _ptr(gate2), _ptr(vstart), _ptr(cos_t),
+            _ptr(sin_t), _ptr(dqkv), _ptr(dgate1), _ptr(dgate2), _ptr(workspace), wbytes, n_seq, S, H, Dh, A, F,
+            dt_code(qkv.dtype), _stream())
     _lib.check(rc, "fvqa_attn_bwd")
     return dqkv
 

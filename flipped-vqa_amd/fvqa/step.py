@@ -310,15 +310,20 @@ class StepEngine:
         for i in range(L):
             x = ar.xs[i]
             # sequence rows, and on the idle CUs the K/V projections of the adapter rows (model.py:98-100)
-            ops.gemm_nt_rider(ar.xn, pk.wqkv[i], ar.qkv[i][:R], rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:],
-                              rider_out=ar.qkv[i][R:, D:])
             g1, g2 = m.gate_views(i)
-            if ops.attn_rope_fused(self.dtype):             # bf16 MFMA build: q,k stay raw, rotated inside
-                ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F,
-                             rope=(self.cos, self.sin))
-            else:
-                ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
+            if ops.rope_in_gemm(self.dtype):                # bf16 MFMA build: q, k rotated where the projection produces them
+                ops.gemm_nt_rope(ar.xn, pk.wqkv[i], ar.qkv[i][:R], (self.cos, self.sin), S, Dh, H,
+                                 rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:], rider_out=ar.qkv[i][R:, D:])
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
+            else:
+                ops.gemm_nt_rider(ar.xn, pk.wqkv[i], ar.qkv[i][:R], rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:],
+                                  rider_out=ar.qkv[i][R:, D:])
+                if ops.attn_rope_fused(self.dtype):         # (FVQA_ROPE_IN_GEMM=0) q,k stay raw, rotated inside
+                    ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F,
+                                 rope=(self.cos, self.sin))
+                else:
+                    ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
+                    ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
             ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)           # h = x + o·Wo^T
             ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
             ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z, st=True)   # z = silu(a)*b; ab[i] <- (s, t)
@@ -393,7 +398,8 @@ class StepEngine:
             dg1, dg2 = grads.gate_grad_views(i)
             if ops.attn_rope_fused(self.dtype):
                 ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1,
-                             dg2, ar.attn_ws, n_seq, S, H, Dh, A, F, rope=(self.cos, self.sin))
+                             dg2, ar.attn_ws, n_seq, S, H, Dh, A, F, rope=(self.cos, self.sin),
+                             prerotated=ops.rope_in_gemm(self.dtype))
             else:
                 ops.attn_bwd(ar.do, ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, sv["vstart"], ar.dqkv, dg1,
                              dg2, ar.attn_ws, n_seq, S, H, Dh, A, F)

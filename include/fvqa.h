@@ -46,6 +46,7 @@ extern "C" {
                                    layout, s = silu(a) = dz/db and t = b*sigma(a)*(1 + a*(1 - sigma(a))) = dz/da: what
                                    the backward of llama/model.py:142 multiplies by */
 #define FVQA_EPI_SWIGLU_BWD_ST 6 /* as 3 with R = that (s, t) buffer: C = dab = (acc * t, acc * s) */
+#define FVQA_EPI_ROPE 7          /* fvqa_gemm_nt_rope only: RoPE of the q | k columns of the QKV projection in the epilogue */
 /* AB16: the layout of every (rows, 2*hidden) buffer that holds the W1 and W3 projections (or their gradients) side by
  * side: column 32k + c is a[16k + c], column 32k + 16 + c is b[16k + c] (c < 16), i.e. the rows of W1 and W3 are
  * interleaved in blocks of 16 in the packed W1|W3 matrix. One MFMA wave of the W1|W3 GEMM then holds a and b of the
@@ -123,6 +124,20 @@ typedef struct fvqa_sk_rider {
 int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
                        int ldc, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The QKV projection with RoPE where it is produced (bf16; reference llama/model.py:61-67 applied to wq(x), wk(x) :89-93):
+ * C[M, N] = A · B^T with columns [0, rope->cols) — the q | k heads, rope->cols = 2 * n_heads * head_dim — rotated by the
+ * tables (rows of head_dim / 2 floats per position, as fvqa_rope_qk takes them) of position (row % seq_len): value rounded to
+ * bf16, rotated in fp32, rounded again, i.e. what fvqa_gemm_nt followed by fvqa_rope_qk leaves (which is what this entry runs
+ * for shapes the persistent kernel does not take; ldc must then be 3 * n_heads * head_dim). M % seq_len == 0. The attention
+ * kernels then read finished operands (cos_t == NULL) and no key tile is rotated once per query block; the backward takes
+ * fvqa_attn_bwd_rotated. `rider` may be NULL. */
+typedef struct fvqa_sk_rope {
+  const float* cos_t; const float* sin_t;
+  int32_t seq_len, head_dim, cols;
+} fvqa_sk_rope;
+int fvqa_gemm_nt_rope(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      const fvqa_sk_rope* rope, const fvqa_sk_rider* rider, void* workspace, size_t workspace_bytes,
+                      void* stream);
 int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
                           int32_t* segs_out, int max_segs);
 /* Measurement probe (bench.py roofline; no reference counterpart): while enabled, launches of the persistent
@@ -168,6 +183,10 @@ int fvqa_swiglu_bwd(const void* dz, const void* ab, void* dab, int rows, int hid
  * kernel rotates them on the fly with the tables of fvqa_rope_qk (identical values to the separate
  * pass; llama/model.py:96); only builds for which fvqa_attn_rope_fused(dtype) == 1 accept them. */
 int fvqa_attn_rope_fused(int dtype);
+/* 1 when the step schedule (fvqa_layers_forward / _backward) rotates q, k in the QKV projection's epilogue (fvqa_gemm_nt_rope):
+ * the arena's qkv rows — the KV cache of the generation path — then hold ROTATED q, k (bf16 MFMA build; FVQA_ROPE_IN_GEMM=0
+ * keeps raw q, k rotated inside the attention kernels). */
+int fvqa_rope_in_gemm(int dtype);
 int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1,
                   const float* gate2, const int32_t* vstart, const float* cos_t, const float* sin_t,
                   int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
@@ -193,6 +212,14 @@ size_t fvqa_attn_bwd_workspace(int n_seq, int seq_len, int n_heads, int head_dim
  * (fvqa_rope_qk inverse follows); with the tables, qkv is raw and dq,dk are gradients of the raw
  * projections. dgate1/dgate2 (H) fp32 are ACCUMULATED (+=). */
 int fvqa_attn_bwd(const void* d_o, const void* qkv, const void* o, const float* lse_a,
+                  const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
+                  const float* cos_t, const float* sin_t,
+                  void* dqkv, float* dgate1, float* dgate2, void* workspace, size_t workspace_bytes,
+                  int n_seq, int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats,
+                  int dtype, void* stream);
+/* As fvqa_attn_bwd with tables, for a `qkv` whose q, k fvqa_gemm_nt_rope has ALREADY rotated: nothing is rotated on load, dq and
+ * dk are conjugate-rotated at the store, so dqkv holds the gradients of the RAW projections (bf16 MFMA build only). */
+int fvqa_attn_bwd_rotated(const void* d_o, const void* qkv, const void* o, const float* lse_a,
                   const float* lse_t, const float* gate1, const float* gate2, const int32_t* vstart,
                   const float* cos_t, const float* sin_t,
                   void* dqkv, float* dgate1, float* dgate2, void* workspace, size_t workspace_bytes,

@@ -214,6 +214,36 @@ def test_gemm_nt_swiglu_st_pair(dtype, M, Hf, D):
     assert rel(gb, db) < tol(dtype, 5e-5, 1.5e-2)
 
 
+@pytest.mark.parametrize("n_seq,S,H,K", [(8, 128, 4, 512), (3, 650, 2, 256), (2, 32, 2, 256), (1, 200, 1, 192)])
+def test_gemm_nt_rope_epilogue(n_seq, S, H, K):
+    """The QKV projection with RoPE in its epilogue (fvqa_gemm_nt_rope; persistent kernel for M >= 192, product + row kernel
+    below that) against gemm_nt followed by rope_qk — the same arithmetic (bf16 value, fp32 rotation, bf16) — and the fp64
+    formula; the adapter rider's rows and the v columns are left alone."""
+    dtype = torch.bfloat16
+    Dh, A = 128, 10
+    D = H * Dh
+    M = n_seq * S
+    x, w = rnd(M, K, dtype=dtype, seed=81), rnd(3 * D, K, dtype=dtype, scale=1 / math.sqrt(K), seed=82)
+    ad = rnd(A, K, dtype=dtype, seed=83)
+    cos, sin = ref_cpu.rope_tables(2 * S, Dh, torch.float32)
+    cd, sd = dev(cos), dev(sin)
+    xd, wd, add = dev(x), dev(w), dev(ad)
+    ref = torch.zeros(M + A, 3 * D, dtype=dtype, device=DEV)
+    ops.gemm_nt(xd, wd, ref[:M])
+    ops.gemm_nt(add, wd[D:], ref[M:, D:])
+    raw = ref.clone()
+    ops.rope_qk(ref, cd, sd, n_seq, S, H, Dh)
+    out = torch.zeros(M + A, 3 * D, dtype=dtype, device=DEV)
+    ops.gemm_nt_rope(xd, wd, out[:M], (cd, sd), S, Dh, H, rider_a=add, rider_b=wd[D:], rider_out=out[M:, D:])
+    assert torch.equal(out[M:], ref[M:]) and torch.equal(out[:M, 2 * D:], ref[:M, 2 * D:])      # rider rows, v columns
+    # fp32 rotation of the same bf16 values: equal up to the contraction of the two products (one bf16 ulp here and there)
+    assert rel(out[:M, :2 * D], ref[:M, :2 * D].double()) < 4e-3
+    assert float((out[:M, :2 * D] != ref[:M, :2 * D]).float().mean()) < 0.02
+    q = raw[:M, :D].double().cpu().view(n_seq, S, H, Dh)
+    qr = ref_cpu.rope_apply(q, cos[:S].double(), sin[:S].double())
+    assert rel(out[:M, :D], qr.reshape(M, D)) < 1e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (1, 520, 256), (16, 1000, 2816), (3, 22016, 1024)])
 def test_gemm_nt_skinny_decode_shape(M, N, K):
     """M <= 16 (one new token per sequence, generation path): the weight-streaming kernel, forced (variant 12)
@@ -443,6 +473,23 @@ def test_attention_fused_rope_bf16(N, S, H, vstart):
 
     of, dqf, dg1f, dg2f, laf, ltf = run(True)
     ou, dqu, dg1u, dg2u, lau, ltu = run(False)
+
+    # third form (the step's, ops.rope_in_gemm): operands rotated beforehand — by the QKV projection's epilogue in the step,
+    # by rope_qk here —, no tables in the forward, the backward un-rotates dq / dk at its store (prerotated=True)
+    buf = qkv_d.clone()
+    ops.rope_qk(buf, cd, sd, N, S, H, Dh)
+    o3 = torch.empty(N * S, D, dtype=dtype, device=DEV)
+    la3 = torch.empty(N * H * S, dtype=torch.float32, device=DEV)
+    lt3 = torch.empty_like(la3)
+    dq3 = torch.full((N * S + A, 3 * D), float("nan"), dtype=dtype, device=DEV)
+    dg13, dg23 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ws3 = torch.zeros(ops.attn_bwd_workspace(N, S, H, Dh, A), dtype=torch.uint8, device=DEV)
+    ops.attn_fwd(buf, o3, la3, lt3, g1d, g2d, vsd, N, S, H, Dh, A, F)
+    ops.attn_bwd(dev(d_o), buf, o3, la3, lt3, g1d, g2d, vsd, dq3, dg13, dg23, ws3, N, S, H, Dh, A, F, rope=(cd, sd),
+                 prerotated=True)
+    # same rotated operands, same conjugate rotation of the fp32 accumulators at the store: the fused form bit for bit
+    assert torch.equal(o3.float().cpu(), of) and torch.equal(dq3.float().cpu(), dqf)
+    assert torch.equal(dg13.cpu(), dg1f) and torch.equal(dg23.cpu(), dg2f)
     # the rotated operands are bit-identical in both runs; only the gradient's un-rotation rounds differently
     assert rel(of, ou) < 1e-5 and rel(laf, lau) < 1e-6 and rel(ltf, ltu) < 1e-6
     assert not torch.isnan(dqf).any()

@@ -453,6 +453,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
   const float g2 = gate2[h];
   const int vs = vstart[n];
   const bool biased_row = vs >= 0 && iq >= vs + F;
+  const bool bias_any = vs >= 0 && i0 + 15 >= vs + F;     // some row of this wave takes the frame bias (wave-uniform)
+  const float sc2 = sc * 1.44269504089f, lst2 = lst * 1.44269504089f, g2l = g2 * 1.44269504089f;   // log2 domain
   f32x4 dq[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -525,18 +527,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
       TrRegs tk;
       tr_issue<true>(sK, 32 * gq, lane, tk);              // Kᵀ fragments return under the exponentials
       float ds[2][4];
+      // (the pass is bound by the vector ALU: a group whose 32 keys lie below every query of the wave, inside the sequence
+      // and outside the frame-bias window takes one FMA + one v_exp_f32 per probability and no mask instructions)
+      const int j0 = kt * BQ + 32 * gq;
+      const bool edge = j0 + 31 > i0 || i0 + 15 >= S || (bias_any && j0 < vs + F && j0 + 31 >= vs);
+      if (!edge) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = kt * BQ + 32 * gq + 16 * c + 4 * g + r;
-          float x = st[c][r] * sc;
-          const bool inwin = biased_row && j >= vs && j < vs + F;
-          if (inwin) x += g2;
-          const float p = (j <= iq && j < S && live) ? __expf(x - lst) : 0.f;
-          ds[c][r] = p * (dpt[c][r] - dt);
-          if (inwin) dg2 += ds[c][r];
-        }
+          for (int r = 0; r < 4; ++r)
+            ds[c][r] = __builtin_amdgcn_exp2f(fmaf(st[c][r], sc2, -lst2)) * (dpt[c][r] - dt);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = j0 + 16 * c + 4 * g + r;
+            float x = fmaf(st[c][r], sc2, -lst2);
+            const bool inwin = biased_row && j >= vs && j < vs + F;
+            if (inwin) x += g2l;
+            const float p = (j <= iq && j < S && live) ? __builtin_amdgcn_exp2f(x) : 0.f;
+            ds[c][r] = p * (dpt[c][r] - dt);
+            if (inwin) dg2 += ds[c][r];
+          }
+      }
       const uint4 sf = pack_blocks(ds[0], ds[1]);
       uint4 kf8[8];
       tr_collect<true>(tk, kf8);
@@ -634,12 +648,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   const int vs = vstart[n];
   const float g2 = gate2[h];
   const bool win_key = vs >= 0 && jk >= vs && jk < vs + F;
+  const bool win_any = vs >= 0 && j0 < vs + F && j0 + 15 >= vs;       // some key of this wave lies in the window (wave-uniform)
+  constexpr float LOG2E = 1.44269504089f;
+  const float sc2 = sc * LOG2E, g2l = g2 * LOG2E;
   for (int t = t_first; t < nqt; ++t) {
     if (t > t_first) __syncthreads();                     // tile t-1 fully consumed
     tile_commit<RIN, BQ>(rQ, sQ, t * BQ, S, cs, sn);
     tile_commit<false, BQ>(rdO, sdO, t * BQ, S, nullptr, nullptr);
     if (threadIdx.x < BQ) {
-      sL[threadIdx.x] = l_in;
+      sL[threadIdx.x] = l_in * LOG2E;                     // probabilities are formed in the log2 domain
       sDl[threadIdx.x] = d_in;
     }
     if (t + 1 < nqt) {                                    // next tile's loads fly under this tile's arithmetic
@@ -674,23 +691,35 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
       tr_issue<true>(sdO, 32 * gq, lane, to);             // dOᵀ / Qᵀ fragments return under the exponentials
       tr_issue<true>(sQ, 32 * gq, lane, tq);
       float p[2][4], ds[2][4];
+      // (vector-ALU bound: sL holds lse * log2(e), so a probability is one FMA + one v_exp_f32; a group whose 32 queries all
+      // lie at or above every key of the wave, inside the sequence, for keys outside the frame-bias window, takes no masks)
+      const int ig0 = t * BQ + 32 * gq;
+      const bool edge = adapter || j0 + 15 > ig0 || ig0 + 31 >= S || j0 + 15 >= S || win_any;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const f32x4 lse4 = *reinterpret_cast<const f32x4*>(sL + 32 * gq + 16 * c + 4 * g);
         const f32x4 dl4 = *reinterpret_cast<const f32x4*>(sDl + 32 * gq + 16 * c + 4 * g);
+        if (!edge) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = t * BQ + 32 * gq + 16 * c + 4 * g + r;      // query row of this register
-          float x = s[c][r] * sc;
-          if (adapter) {
-            const float pp = (kok && i < S) ? __expf(x - lse4[r]) : 0.f;
-            ds[c][r] = pp * (g1 * dp[c][r] - dl4[r]);
-            p[c][r] = pp * g1;
-          } else {
-            if (win_key && i >= vs + F) x += g2;
-            const float pp = (jk <= i && i < S && kok) ? __expf(x - lse4[r]) : 0.f;
-            ds[c][r] = pp * (dp[c][r] - dl4[r]);
-            p[c][r] = pp;
+          for (int r = 0; r < 4; ++r) {
+            p[c][r] = __builtin_amdgcn_exp2f(fmaf(s[c][r], sc2, -lse4[r]));
+            ds[c][r] = p[c][r] * (dp[c][r] - dl4[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ig0 + 16 * c + 4 * g + r;                 // query row of this register
+            float x = fmaf(s[c][r], sc2, -lse4[r]);
+            if (adapter) {
+              const float pp = (kok && i < S) ? __builtin_amdgcn_exp2f(x) : 0.f;
+              ds[c][r] = pp * (g1 * dp[c][r] - dl4[r]);
+              p[c][r] = pp * g1;
+            } else {
+              if (win_key && i >= vs + F) x += g2l;
+              const float pp = (jk <= i && i < S && kok) ? __builtin_amdgcn_exp2f(x) : 0.f;
+              ds[c][r] = pp * (dp[c][r] - dl4[r]);
+              p[c][r] = pp;
+            }
           }
         }
       }

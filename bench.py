@@ -369,11 +369,11 @@ def main():
         torch.cuda.synchronize()
         gaps = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(128))
         probe_overhead_us = gaps[len(gaps) // 2]
-        epi_name = {0: "none", 1: "residual", 3: "swiglu_bwd", 4: "swiglu_fwd", 5: "swiglu_fwd_st", 6: "swiglu_bwd_st"}
+        epi_name = {0: "none", 1: "residual", 3: "swiglu_bwd", 4: "swiglu_fwd", 5: "swiglu_fwd_st", 6: "swiglu_bwd_st", 7: "rope"}
 
         def name_of(kind):
             return ("f32" if kind & 64 else "bf16") + "_" + ("f32" if kind & 32 else "bf16") + "_" + \
-                epi_name.get(kind & 15, str(kind & 15)) + ("_splitk" if kind & 16 else "")
+                epi_name.get(kind & 15, str(kind & 15)) + ("_splitk" if kind & 16 else "") + ("_4w" if kind & 128 else "")
 
         def summarise(rec):
             """per (kind, FLOPs) = per shape of an instantiation: launches per step, mean duration of the bracketed ones"""

@@ -372,7 +372,8 @@ extern "C" int fvqa_gemm_nt_rope(const void* A, const void* B, void* C, int M, i
 }
 
 static int swiglu_fwd_impl(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K, int lda, int ldb,
-                           int dtype, void* workspace, size_t workspace_bytes, void* stream, int epilogue) {
+                           int dtype, void* workspace, size_t workspace_bytes, void* stream, int epilogue,
+                           const fvqa_sk_rider* rider = nullptr) {
   if (!A || !B13 || !ab || !z || !fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
   const int N = 2 * hidden;
   const int ke = dtype == FVQA_BF16 ? 64 : 32;
@@ -382,8 +383,23 @@ static int swiglu_fwd_impl(const void* A, const void* B13, void* ab, void* z, in
       ((size_t)lda * es & 15) || ((size_t)ldb * es & 15) || !workspace || ((uintptr_t)workspace & 255) ||
       workspace_bytes < fvqa_gemm_sk_workspace())
     return FVQA_EALIGN;
-  return fvqa_gemm_sk_impl(A, B13, ab, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, N, dtype, dtype,
-                           epilogue, (hipStream_t)stream, nullptr, nullptr, z);
+  if (rider && (!rider->A || !rider->B || !rider->C || rider->M <= 0 || rider->N <= 0 || rider->K <= 0)) return FVQA_EINVAL;
+  int rode = 0;
+  const int rc = fvqa_gemm_sk_impl(A, B13, ab, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, N, dtype, dtype,
+                                   epilogue, (hipStream_t)stream, rider, &rode, z);
+  if (rc || rode || !rider) return rc;
+  if (rider->accumulate_f32)
+    return fvqa_gemm_nt(rider->A, rider->B, nullptr, nullptr, (float*)rider->C, rider->M, rider->N, rider->K, rider->lda,
+                        rider->ldb, rider->ldc, 0, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+  return fvqa_gemm_nt(rider->A, rider->B, rider->C, nullptr, nullptr, rider->M, rider->N, rider->K, rider->lda, rider->ldb,
+                      rider->ldc, rider->M, dtype, dtype, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+}
+
+extern "C" int fvqa_gemm_nt_swiglu_fwd_st_rider(const void* A, const void* B13, void* st, void* z, int M, int hidden, int K,
+                                                int lda, int ldb, int dtype, const fvqa_sk_rider* rider, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  return swiglu_fwd_impl(A, B13, st, z, M, hidden, K, lda, ldb, dtype, workspace, workspace_bytes, stream,
+                         FVQA_EPI_SWIGLU_FWD_ST, rider);
 }
 
 extern "C" int fvqa_gemm_nt_swiglu_fwd(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K,

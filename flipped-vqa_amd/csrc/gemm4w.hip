@@ -1,0 +1,161 @@
+// 4-wave projection GEMM for gfx950 (bf16): one 256-thread workgroup per CU, ONE wave per SIMD, each wave 64 rows x the
+// whole width of a 256 x (16*NBT) output tile with its accumulators in the accumulator half of the register file
+// (main loop: gemm4w_loop.h / generated gemm4w_asm.h). Whole tiles only — no split along K, no exchange: it takes the
+// projections whose outputs are wide enough to fill the chip with whole tiles (reference llama/model.py:89 q|k|v, :142
+// w1|w3 and the dX of w2, :348 the LM head), and picks the tile WIDTH per problem (256 / 192 / 176 columns) so that the tile
+// count lands on a multiple of the CU count: 12288 columns = 64 x 192 (256 tiles of 256 rows at M = 1024 instead of 192),
+// 11008 = 57.3 x 192 (232 tiles instead of 172), 22016 = 114.7 x 192 (460 = 1.8 rounds instead of a whole round + a round of
+// half tiles that exchange partial sums). The N = 4096 outputs (64 tiles for 256 CUs) stay with the split-K kernel of
+// gemm_sk.hip, as does the fp32 build.
+//
+// Epilogues (applied to finished tiles staged through the wave's share of the idle ring memory so that every global
+// access is a whole 16-byte chunk of a row): none (bf16 or fp32 out), + residual, RoPE of the q | k columns, SwiGLU forward
+// with the backward's factors saved (W1 | W3 columns interleaved in blocks of 16, "AB16"), SwiGLU' (dH W2^T). Same
+// arithmetic, element for element, as the epilogues of gemm_sk.hip (the two kernels produce bitwise-equal whole tiles).
+//
+// Rider: a second product of <= 16 rows (gemm_skinny.h) runs inside the launch on the workgroups that have no tile in the
+// last round ("light" workgroups), spread over the XCDs by the same slot map that keeps the m tiles of a weight panel on
+// one XCD.
+#include "gemm4w_kernel.h"
+#include "probe.h"
+#include <atomic>
+#include <cstdlib>
+
+namespace {
+using namespace fvqa_g4;
+
+template <int NBT, typename TO, int EPI>
+int launch4(const G4Args& a, hipStream_t st) {
+  auto k = gemm4w_k<NBT, TO, EPI>;
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done.load()) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<NBT>::RING_BYTES);
+    attr_done.store(true);
+  }
+  {
+    FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (sizeof(TO) == 4 ? 32 : 0) | 128);       // kind bit 7: the 4-wave kernel
+    hipLaunchKernelGGL(k, dim3(a.grid), dim3(256), Geo<NBT>::RING_BYTES, st, a);
+  }
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+template <int NBT>
+int dispatch4(const G4Args& a, int out_dtype, int epilogue, hipStream_t st) {
+  if (out_dtype == FVQA_F32) return launch4<NBT, float, FVQA_EPI_NONE>(a, st);
+  switch (epilogue) {
+    case FVQA_EPI_NONE: return launch4<NBT, bf16_t, FVQA_EPI_NONE>(a, st);
+    case FVQA_EPI_RESIDUAL: return launch4<NBT, bf16_t, FVQA_EPI_RESIDUAL>(a, st);
+    case FVQA_EPI_ROPE: return launch4<NBT, bf16_t, FVQA_EPI_ROPE>(a, st);
+    case FVQA_EPI_SWIGLU_BWD_ST: return launch4<NBT, bf16_t, FVQA_EPI_SWIGLU_BWD_ST>(a, st);
+    case FVQA_EPI_SWIGLU_FWD_ST:
+      if constexpr (NBT % 2 == 0) return launch4<NBT, bf16_t, FVQA_EPI_SWIGLU_FWD_ST>(a, st);
+      else return FVQA_EINVAL;
+    default: return FVQA_EINVAL;
+  }
+}
+
+}  // namespace
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+// Estimated launch time (us) of an (M, N, K) problem with tiles of 16*nbt columns on n_cu CUs, fitted to the launch times of
+// the C2 projections on an MI355X (profiles/r04_gemm4w.log): whole rounds of tiles; a round's time grows with the tile width
+// and, sub-linearly, with the number of busy CUs (the chip holds a higher clock with fewer of them: 0.865 of the full-chip
+// tile time with 192 busy, 0.82 with 172); an epilogue term per round; a rider streams its weight rows at ~23 GB/s per light
+// workgroup from the start of the last round (measured 22-25 under the load of the busy CUs) and is a launch of its own
+// (~3.2 TB/s + 10 us) when fewer than 8 workgroups are light.
+static double g4_cost_us(int M, int N, int K, int nbt, int epilogue, int out_dtype, const fvqa_sk_rider* rider, int n_cu,
+                         int* light_out) {
+  const int tm = (M + 255) / 256, tn = (N + 16 * nbt - 1) / (16 * nbt);
+  const int tiles = tm * tn;
+  const int rounds = (tiles + n_cu - 1) / n_cu;
+  const int last = tiles - (rounds - 1) * n_cu;
+  const int light = n_cu - last;
+  const double t256 = 101.0 * K / 4096.0;
+  const double eff = nbt == 11 ? 1.04 : 1.0;
+  double epi = out_dtype == FVQA_F32 ? 4.0 : 4.0;
+  if (epilogue == FVQA_EPI_ROPE || epilogue == FVQA_EPI_RESIDUAL) epi = 9.0;
+  if (epilogue == FVQA_EPI_SWIGLU_FWD_ST) epi = 7.0;
+  if (epilogue == FVQA_EPI_SWIGLU_BWD_ST) epi = 17.0;
+  auto round_us = [&](int busy) { return t256 * (nbt / 16.0) * (0.46 + 0.54 * busy / (double)n_cu) * eff + epi * (nbt / 16.0); };
+  const double head = (rounds - 1) * round_us(n_cu);
+  double total = head + round_us(last);
+  if (rider) {
+    const double bytes = 2.0 * rider->N * (double)rider->K;
+    if (light >= 8) {
+      const double t_r = head + bytes / (light * 23.0e3) + 3.0;
+      if (t_r > total) total = t_r;
+    } else {
+      total += 10.0 + bytes / 3.2e6;
+    }
+  }
+  if (light_out) *light_out = light;
+  return total;
+}
+
+// Tile width (in 16-column blocks) the 4-wave kernel would use, 0 when the problem is not its to take.
+extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider,
+                                  int n_cu) {
+  static const char* env = getenv("FVQA_GEMM4W");
+  if (env && env[0] == '0') return 0;
+  if (dtype != FVQA_BF16 || (out_dtype != FVQA_BF16 && out_dtype != FVQA_F32)) return 0;
+  if (out_dtype == FVQA_F32 && epilogue != FVQA_EPI_NONE) return 0;
+  if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_ROPE &&
+      epilogue != FVQA_EPI_SWIGLU_FWD_ST && epilogue != FVQA_EPI_SWIGLU_BWD_ST)
+    return 0;
+  if (M < 192 || N < 256 || (K % 64) || (N & 7) || n_cu < 8 || n_cu > 256) return 0;
+  static const char* force = getenv("FVQA_GEMM4W_NBT");
+  int best = 0;
+  double best_c = 1e30;
+  for (int nbt : {16, 14, 13, 12, 11}) {
+    if (force && force[0] && atoi(force) != nbt) continue;
+    if (epilogue == FVQA_EPI_SWIGLU_FWD_ST && (nbt & 1)) continue;     // (a, b) pairs of 16-column blocks must not straddle tiles
+    const double c = g4_cost_us(M, N, K, nbt, epilogue, out_dtype, rider, n_cu, nullptr);
+    if (c < best_c) { best_c = c; best = nbt; }
+  }
+  return best;
+}
+
+// C[M,N] = A[M,K] x B[N,K]^T with the epilogue applied per finished tile (bf16 operands). The caller (fvqa_gemm_sk_impl)
+// has validated pointers, alignment and leading dimensions. *rode <- 1 when the rider ran inside the launch.
+int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
+                     int ldc, int out_dtype, int epilogue, hipStream_t st, const fvqa_sk_rider* rider, int* rode, void* C2,
+                     const fvqa_sk_rope* rope, int n_cu) {
+  if (rode) *rode = 0;
+  if ((size_t)M * lda * 2 >= 0x7fffffffull || (size_t)N * ldb * 2 >= 0x7fffffffull) return FVQA_ESHAPE;   // 32-bit DMA offsets
+  G4Args a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.R = (const bf16_t*)R; a.C2 = C2;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.tm = (M + 255) / 256;
+  a.tn = (N + 16 * nbt - 1) / (16 * nbt);
+  a.tiles = a.tm * a.tn;
+  a.rider = G4Rider{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
+  a.rope_cos = rope ? rope->cos_t : nullptr; a.rope_sin = rope ? rope->sin_t : nullptr;
+  a.rope_S = rope ? rope->seq_len : 1; a.rope_cols = rope ? rope->cols : 0; a.rope_hp = rope ? rope->head_dim / 2 : 1;
+  a.rope_hmask = (rope && (rope->head_dim & (rope->head_dim - 1)) == 0) ? rope->head_dim - 1 : 0;
+  static const bool ride = !(getenv("FVQA_RIDER") && getenv("FVQA_RIDER")[0] == '0');
+  const bool rider_ok = ride && rider && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 && rider->N > 0 &&
+                        rider->A && rider->B && rider->C;
+  a.grid = a.tiles < n_cu ? a.tiles : n_cu;
+  if (rider_ok) a.grid = n_cu;                                // light workgroups exist only on a full grid
+  a.rounds = (a.tiles + a.grid - 1) / a.grid;
+  if (rider_ok) {
+    const int light = a.grid - (a.tiles - (a.rounds - 1) * a.grid);
+    if (light >= 8) {
+      a.rider = G4Rider{rider->A, rider->B, rider->C, rider->M, rider->N, rider->K, rider->lda, rider->ldb, rider->ldc,
+                        rider->accumulate_f32, 1};
+      if (rode) *rode = 1;
+    } else {
+      a.grid = a.tiles < n_cu ? a.tiles : n_cu;
+      a.rounds = (a.tiles + a.grid - 1) / a.grid;
+    }
+  }
+  switch (nbt) {
+    case 16: return dispatch4<16>(a, out_dtype, epilogue, st);
+    case 14: return dispatch4<14>(a, out_dtype, epilogue, st);
+    case 13: return dispatch4<13>(a, out_dtype, epilogue, st);
+    case 12: return dispatch4<12>(a, out_dtype, epilogue, st);
+    case 11: return dispatch4<11>(a, out_dtype, epilogue, st);
+    default: return FVQA_EINVAL;
+  }
+}

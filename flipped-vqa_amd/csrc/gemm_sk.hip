@@ -91,6 +91,16 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 #define SK_STAMP(slot) do { } while (0)
 #endif
 
+// Diagnostic build (-DFVQA_SK_CLOCK, tools/sk_clock.py): the shader clock INSIDE the ring loop, as MI355X_MICROARCH.md
+// "DVFS give-back" item 6 prescribes: s_memtime (shader cycles) and s_memrealtime (100 MHz) stamped once before and once
+// after the loop of every workgroup's first segment; clock = d(memtime) / d(memrealtime) x 100 MHz. Each launch writes to
+// its own slice of a 512-launch ring behind the slabs (memory nothing else in the kernel reads), so a whole step of
+// back-to-back launches can be read out afterwards. The shipping build compiles none of it.
+#ifdef FVQA_SK_CLOCK
+constexpr int CLOCK_RING = 512;
+#define SK_CLOCK(t_, r_) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_) :: "memory")
+#endif
+
 // column of a[c] in an AB16 row (W1 | W3 projections interleaved in 16-column blocks; b[c] sits 16 columns further on)
 __device__ __forceinline__ size_t ab16(int c) { return (size_t)(c >> 4) * 32 + (c & 15); }
 
@@ -472,8 +482,27 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef FVQA_SK_CLOCK
+    u64 ct0, cr0, ct1, cr1;
+    __builtin_amdgcn_sched_barrier(0);
+    SK_CLOCK(ct0, cr0);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     ring_loop<T, 4>(acc, smem, (const T*)a.A, (const T*)a.B, a.M, a.N, a.lda, a.ldb, m0, n0,
                     (size_t)s.k0 * 2 * KE, s.k1 - s.k0, w, lane, rowxor);
+#ifdef FVQA_SK_CLOCK
+    __builtin_amdgcn_sched_barrier(0);
+    SK_CLOCK(ct1, cr1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid == 0 && idx == 0) {
+      u64* st_ = a.stamps + (size_t)wid * 16;
+      st_[0] = ct0; st_[1] = cr0; st_[2] = ct1; st_[3] = cr1;
+      st_[4] = ((u64)(unsigned)a.N << 32) | (unsigned)a.K;
+      st_[5] = a.epoch;
+      st_[6] = (u64)EPI | ((u64)s.n << 8) | ((u64)(s.k1 - s.k0) << 16) | ((u64)sizeof(TO) << 40) | ((u64)n_main << 48);
+      st_[7] = (u64)a.M;
+    }
+#endif
     SK_STAMP(1);
     // Everything below is addressed from opaque copies of (lane, wave, tile origin): otherwise hipcc hoists the
     // epilogue's per-lane address arithmetic above the ring loop and pays for it with spills INSIDE that loop.
@@ -537,7 +566,11 @@ int cu_count() {                                          // of the CURRENT devi
 
 }  // namespace
 
+#ifdef FVQA_SK_CLOCK
+constexpr size_t STAMP_BYTES = (size_t)CLOCK_RING * 256 * 16 * sizeof(u64);
+#else
 constexpr size_t STAMP_BYTES = 256 * 16 * sizeof(u64);
+#endif
 extern "C" size_t fvqa_gemm_sk_workspace(void) {
   return SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float) + STAMP_BYTES;
 }
@@ -566,6 +599,13 @@ extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, i
   return n;
 }
 
+// the 4-wave whole-tile kernel (gemm4w.hip)
+extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider,
+                                  int n_cu);
+int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
+                     int ldc, int out_dtype, int epilogue, hipStream_t st, const fvqa_sk_rider* rider, int* rode, void* C2,
+                     const fvqa_sk_rope* rope, int n_cu);
+
 // C[M,N] = A[M,K] x B[N,K]^T with the epilogue applied once per finished tile. `ws`: fvqa_gemm_sk_workspace()
 // bytes whose first 4096 were zeroed once by the caller after allocation (epoch flags; never reset afterwards).
 // rider (may be NULL): see SkRider; *rode <- 1 when it was put on this launch's idle CUs (>= 16 of them, bf16), else 0
@@ -589,6 +629,17 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   SkArgs a;
   a.A = A; a.B = B; a.C = C; a.R = R; a.C2 = C2;
   if ((epilogue == FVQA_EPI_SWIGLU_FWD || epilogue == FVQA_EPI_SWIGLU_FWD_ST) && (!C2 || (N & 31) || ((uintptr_t)C2 & 15) || out_dtype != dtype)) return FVQA_EINVAL;
+  if (dtype == FVQA_BF16) {
+    // Outputs wide enough to fill the chip with whole tiles go to the 4-wave kernel (gemm4w.hip: one wave per SIMD, tile
+    // width chosen per problem); a launch this kernel would split along K in full (N = 4096 outputs at M = 1024: 64 tiles
+    // for 256 CUs) stays here.
+    const int cus = n_cu < 256 ? n_cu : 256;
+    const fvqa_sk_plan p0 = fvqa_sk_make_plan(M, N, K, 64, cus);
+    if (!(p0.full == 0 && p0.s > 1)) {
+      const int nbt = fvqa_gemm4w_choose(M, N, K, dtype, out_dtype, epilogue, rider, cus);
+      if (nbt) return fvqa_gemm4w_impl(nbt, A, B, C, R, M, N, K, lda, ldb, ldc, out_dtype, epilogue, st, rider, rode, C2, rope, cus);
+    }
+  }
   a.sync = (u64*)ws;
   a.slabs = (float*)((char*)ws + SYNC_BYTES);
   a.stamps = (u64*)((char*)ws + SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float));
@@ -596,6 +647,9 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   a.plan = fvqa_sk_make_plan(M, N, K, dtype == FVQA_BF16 ? 64 : 32, n_cu < 256 ? n_cu : 256);
   if (a.plan.n_teams * a.plan.ts > 256 || a.plan.n_teams * a.plan.ts > n_cu) return FVQA_ESHAPE;
   a.epoch = g_epoch.fetch_add(1) + 1;
+#ifdef FVQA_SK_CLOCK
+  a.stamps += (size_t)(a.epoch % CLOCK_RING) * 256 * 16;
+#endif
   a.rider = SkRider{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
   a.rope_cos = rope ? rope->cos_t : nullptr; a.rope_sin = rope ? rope->sin_t : nullptr;
   a.rope_S = rope ? rope->seq_len : 1; a.rope_cols = rope ? rope->cols : 0; a.rope_hp = rope ? rope->head_dim / 2 : 1;

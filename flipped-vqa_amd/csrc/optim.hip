@@ -157,5 +157,5 @@ extern "C" int fvqa_scaler_update(float* step, float* scale, float* growth_track
   return FVQA_OK;
 }
 
-extern "C" int fvqa_version(void) { return 11; }
+extern "C" int fvqa_version(void) { return 12; }
 extern "C" const char* fvqa_arch(void) { return "gfx950"; }

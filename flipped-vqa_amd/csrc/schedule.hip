@@ -47,6 +47,16 @@ extern "C" int fvqa_rope_in_gemm(int dtype) {
   return fvqa_attn_rope_fused(dtype) != 0 && !off ? 1 : 0;
 }
 
+extern "C" int fvqa_swiglu_st(void) { return swiglu_st() ? 1 : 0; }
+
+// 1: the adapter K/V rows of layer i+1 are the rider of layer i's W1|W3 launch (layer 0's: a launch of their own before the
+// walk). They depend on parameters only, and that launch — 1.8 rounds of whole tiles in the 4-wave kernel — has workgroups
+// without a tile in its last round, while the QKV launch fills the chip with whole tiles (gemm4w.hip).
+extern "C" int fvqa_kv_rider_ahead(int dtype) {
+  static const bool off = [] { const char* e = getenv("FVQA_KV_AHEAD"); return e && e[0] == '0'; }();
+  return fvqa_rope_in_gemm(dtype) != 0 && swiglu_st() && !off ? 1 : 0;
+}
+
 namespace {
 
 int check_plan_dims_only(const fvqa_layer_plan* p) {
@@ -104,10 +114,23 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
   const size_t es = fvqa_dtype_size(dt);
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
   const bool rope_gemm = fvqa_rope_in_gemm(dt) != 0;
+  const bool kv_ahead = fvqa_kv_rider_ahead(dt) != 0;
   if (!p->adapter_c) return FVQA_EINVAL;
   // the adapter prompts of all walked layers in storage dtype (model.py:339 `.half()`), one launch
   RUN(fvqa_cast_rows(p->adapter, p->adapter_c, L * A, D, dt, stream));
   RUN(fvqa_rmsnorm_fwd(p->xs, p->an[0], p->xn, p->rstd1, R, D, p->eps, dt, stream));
+  // the A adapter rows under the sequence rows of layer i's qkv get their K and V projections (model.py:98-100; their q block
+  // is never read) as a rider: beside layer i's QKV GEMM, or (kv_ahead) beside layer i-1's W1|W3 GEMM
+  auto kv_rider = [&](int i) {
+    void* qkv_i = at(p->qkv, (size_t)i * Ra * 3 * D, es);
+    return fvqa_sk_rider{at(p->adapter_c, (size_t)i * A * D, es), at(p->wqkv[i], (size_t)D * D, es),
+                         at(qkv_i, (size_t)R * 3 * D + D, es), A, 2 * D, D, D, D, 3 * D, 0};
+  };
+  if (kv_ahead) {
+    const fvqa_sk_rider kv0 = kv_rider(0);
+    RUN(fvqa_gemm_nt(kv0.A, kv0.B, kv0.C, nullptr, nullptr, kv0.M, kv0.N, kv0.K, kv0.lda, kv0.ldb, kv0.ldc, kv0.M, dt, dt,
+                     FVQA_EPI_NONE, 0, nullptr, 0, stream));
+  }
   for (int i = 0; i < L; ++i) {
     const void* x = at(p->xs, (size_t)i * R * D, es);
     void* x_next = at(p->xs, (size_t)(i + 1) * R * D, es);
@@ -117,13 +140,11 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
     void* ab = at(p->ab, (size_t)i * R * 2 * Hf, es);
     float* lse_a = p->lse_a + (size_t)i * n_seq * H * S;
     float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
-    // the A adapter rows under the sequence rows of qkv get their K and V projections (model.py:98-100; their q block
-    // is never read) on the CUs the QKV GEMM leaves idle
-    const fvqa_sk_rider kv = {at(p->adapter_c, (size_t)i * A * D, es), at(p->wqkv[i], (size_t)D * D, es),
-                              at(qkv, (size_t)R * 3 * D + D, es), A, 2 * D, D, D, D, 3 * D, 0};
+    const fvqa_sk_rider kv = kv_rider(i);
     if (rope_gemm) {                                   // bf16 MFMA build: q, k are rotated where the projection produces them
       const fvqa_sk_rope rp = {p->cos_t, p->sin_t, S, Dh, 2 * D};
-      RUN(fvqa_gemm_nt_rope(p->xn, p->wqkv[i], qkv, R, 3 * D, D, D, D, 3 * D, &rp, &kv, p->gemm_ws, p->gemm_ws_bytes, stream));
+      RUN(fvqa_gemm_nt_rope(p->xn, p->wqkv[i], qkv, R, 3 * D, D, D, D, 3 * D, &rp, kv_ahead ? nullptr : &kv, p->gemm_ws,
+                            p->gemm_ws_bytes, stream));
       RUN(fvqa_attn_fwd(qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, nullptr, nullptr, n_seq, S, H, Dh, A,
                         p->max_feats, dt, stream));
     } else {
@@ -143,7 +164,11 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
                      p->gemm_ws_bytes, stream));
     RUN(fvqa_rmsnorm_fwd(h, p->fn[i], p->hn, p->rstd2 + (size_t)i * R, R, D, p->eps, dt, stream));
     // z = silu(a)*b with (a | b) = hn·(W1|W3)^T (model.py:142) in one launch; `ab` keeps the backward's factors (s, t)
-    if (swiglu_st())
+    if (kv_ahead && i + 1 < L) {
+      const fvqa_sk_rider kvn = kv_rider(i + 1);
+      RUN(fvqa_gemm_nt_swiglu_fwd_st_rider(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, &kvn, p->gemm_ws, p->gemm_ws_bytes,
+                                           stream));
+    } else if (swiglu_st())
       RUN(fvqa_gemm_nt_swiglu_fwd_st(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
     else
       RUN(fvqa_gemm_nt_swiglu_fwd(p->hn, p->w13[i], ab, p->z, R, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST = 0, 1, 3, 6
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -25,6 +25,9 @@ SIGNATURES = {
     "fvqa_gemm_sk_workspace": (_sz, []),
     "fvqa_gemm_nt_swiglu_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "fvqa_gemm_nt_swiglu_fwd_st": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "fvqa_gemm_nt_swiglu_fwd_st_rider": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "fvqa_kv_rider_ahead": (_i, [_i]),
+    "fvqa_swiglu_st": (_i, []),
     "fvqa_gemm_nt_rider": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "fvqa_gemm_sk_describe": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i]),
     "fvqa_gemm_timing_enable": (_i, [_i]),

@@ -214,11 +214,14 @@ def gemm_timing_read():
     return [(float(us[i]), float(fl[i]), int(kd[i])) for i in range(min(n, got))]
 
 
-def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: torch.Tensor, st: bool = False):
+def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: torch.Tensor, st: bool = False, *,
+                       rider_a=None, rider_b=None, rider_out=None):
     """ab (M, 2*Hf) = x @ w13^T and z (M, Hf) = silu(a) * b in one launch; w13 / ab in the AB16 layout (pack_ab16).
     st=True (the training step): `ab` receives the backward's factors s = silu(a), t = dz/da in the a and b slots
-    (FVQA_EPI_SWIGLU_FWD_ST), to be consumed by gemm_nt_swiglu_bwd(..., st=True)."""
+    (FVQA_EPI_SWIGLU_FWD_ST), to be consumed by gemm_nt_swiglu_bwd(..., st=True). Optional rider (st=True only; <= 16 rows,
+    rider_out = rider_a @ rider_b^T in the operands' dtype) as gemm_nt_rider."""
     _dev(x, w13, ab, z)
+    _dev(rider_a, rider_b, rider_out, rows_strided=True)
     M, K = x.shape
     N = w13.shape[0]
     _need(w13.shape[1] == K and N % 32 == 0 and x.dtype == w13.dtype == ab.dtype == z.dtype, "gemm_nt_swiglu_fwd: operands")
@@ -226,6 +229,20 @@ def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: 
           "gemm_nt_swiglu_fwd: ab / z shape")
     lib = _lib.load()
     ws = gemm_workspace(x.device, int(lib.fvqa_gemm_sk_workspace()))
+    if rider_a is not None:
+        _need(st, "gemm_nt_swiglu_fwd: a rider needs st=True")
+        M2, K2 = rider_a.shape
+        N2 = rider_b.shape[0]
+        _need(rider_b.shape[1] == K2 and tuple(rider_out.shape) == (M2, N2) and M2 <= 16 and
+              rider_a.dtype == rider_b.dtype == rider_out.dtype == x.dtype and
+              rider_a.stride(1) == rider_b.stride(1) == rider_out.stride(1) == 1, "gemm_nt_swiglu_fwd: rider")
+        rd = _lib.SkRider(rider_a.data_ptr(), rider_b.data_ptr(), rider_out.data_ptr(), M2, N2, K2, rider_a.stride(0),
+                          rider_b.stride(0), rider_out.stride(0), 0)
+        import ctypes as C
+        rc = lib.fvqa_gemm_nt_swiglu_fwd_st_rider(_ptr(x), _ptr(w13), _ptr(ab), _ptr(z), M, N // 2, K, K, K, dt_code(x.dtype),
+                                                  C.byref(rd), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "fvqa_gemm_nt_swiglu_fwd_st_rider")
+        return z
     fn = lib.fvqa_gemm_nt_swiglu_fwd_st if st else lib.fvqa_gemm_nt_swiglu_fwd
     rc = fn(_ptr(x), _ptr(w13), _ptr(ab), _ptr(z), M, N // 2, K, K, K, dt_code(x.dtype), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "fvqa_gemm_nt_swiglu_fwd")
@@ -349,6 +366,17 @@ def _attn_shapes(qkv, n_seq, S, H, Dh, A):
           f"attention: qkv must be ({n_seq * S + A}, {3 * D}), got {tuple(qkv.shape)}")
     _need(Dh == 128 and 1 <= A <= 16, "attention: head_dim must be 128 and adapter_len <= 16")
     return D
+
+
+def kv_rider_ahead(dtype: torch.dtype) -> bool:
+    """True when the step computes the adapter K/V rows of layer i+1 as the rider of layer i's W1|W3 launch (layer 0's as a
+    launch of its own before the walk) instead of beside layer i+1's QKV projection (csrc/schedule.hip)."""
+    return bool(_lib.load().fvqa_kv_rider_ahead(dt_code(dtype)))
+
+
+def swiglu_st() -> bool:
+    """True unless FVQA_SWIGLU_AB=1: the W1|W3 launch saves the SwiGLU backward's factors (s, t) instead of (a, b)."""
+    return bool(_lib.load().fvqa_swiglu_st())
 
 
 def rope_in_gemm(dtype: torch.dtype) -> bool:

@@ -307,13 +307,18 @@ class StepEngine:
         adapter = m.adapter_query.weight.data.view(-1, A, D)     # (adapter_layer, A, D); model.py:304
         ops.cast_rows(adapter.reshape(L * A, D), ar.adapter_c.view(L * A, D))
         ops.rmsnorm_fwd(ar.xs[0], pk.an[0], ar.xn, ar.rstd1[0], self.eps, rows=R)
+        # the K/V projections of the adapter rows (model.py:98-100) ride on a projection launch: layer i's QKV, or (kv_ahead)
+        # layer i-1's W1|W3 — they depend on parameters only; layer 0's then is a launch of its own
+        kv_ahead = ops.kv_rider_ahead(self.dtype)
+        st = ops.swiglu_st()
+        if kv_ahead:
+            ops.gemm_nt(ar.adapter_c[0], pk.wqkv[0][D:], ar.qkv[0][R:, D:])
         for i in range(L):
             x = ar.xs[i]
-            # sequence rows, and on the idle CUs the K/V projections of the adapter rows (model.py:98-100)
             g1, g2 = m.gate_views(i)
             if ops.rope_in_gemm(self.dtype):                # bf16 MFMA build: q, k rotated where the projection produces them
-                ops.gemm_nt_rope(ar.xn, pk.wqkv[i], ar.qkv[i][:R], (self.cos, self.sin), S, Dh, H,
-                                 rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:], rider_out=ar.qkv[i][R:, D:])
+                kv = {} if kv_ahead else dict(rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:], rider_out=ar.qkv[i][R:, D:])
+                ops.gemm_nt_rope(ar.xn, pk.wqkv[i], ar.qkv[i][:R], (self.cos, self.sin), S, Dh, H, **kv)
                 ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
             else:
                 ops.gemm_nt_rider(ar.xn, pk.wqkv[i], ar.qkv[i][:R], rider_a=ar.adapter_c[i], rider_b=pk.wqkv[i][D:],
@@ -326,7 +331,11 @@ class StepEngine:
                     ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
             ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)           # h = x + o·Wo^T
             ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
-            ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z, st=True)   # z = silu(a)*b; ab[i] <- (s, t)
+            if kv_ahead and i + 1 < L:      # z = silu(a)*b; ab[i] <- (s, t); rider: the next layer's adapter K/V rows
+                ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z, st=True, rider_a=ar.adapter_c[i + 1],
+                                       rider_b=pk.wqkv[i + 1][D:], rider_out=ar.qkv[i + 1][R:, D:])
+            else:
+                ops.gemm_nt_swiglu_fwd(ar.hn, pk.w13[i], ar.ab[i], ar.z, st=st)
             ops.gemm_nt(ar.z, pk.w2[i], ar.xs[i + 1], residual=ar.h[i])   # x' = h + z·W2^T
             if i + 1 < L:
                 ops.rmsnorm_fwd(ar.xs[i + 1], pk.an[i + 1], ar.xn, ar.rstd1[i + 1], self.eps, rows=R)
@@ -385,12 +394,13 @@ class StepEngine:
         t = ar.dz.view(-1)[: R * D].view(R, D)
         ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
         g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
+        st = ops.swiglu_st()                 # (FVQA_SWIGLU_AB=1 switches BOTH schedules to the a, b form)
         for i in reversed(range(L)):
             if i + 1 < L:                    # dz·SwiGLU' in the epilogue; rider: the previous layer's adapter-grad rows
-                ops.gemm_nt_rider(cur, pk.w2_t[i], ar.dab, swiglu_ab=ar.ab[i], swiglu_st=True, rider_a=ar.dqkv[R:, D:],
+                ops.gemm_nt_rider(cur, pk.w2_t[i], ar.dab, swiglu_ab=ar.ab[i], swiglu_st=st, rider_a=ar.dqkv[R:, D:],
                                   rider_b=pk.wqkv_t[i + 1][:, D:], rider_out=g_adapter[i + 1], accumulate=True)
             else:
-                ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab, st=True)
+                ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab, st=st)
             ops.gemm_nt(ar.dab, pk.w13_t[i], t)
             ops.rmsnorm_bwd(t, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
             ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)

@@ -124,6 +124,13 @@ typedef struct fvqa_sk_rider {
 int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
                        int ldc, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* fvqa_gemm_nt_swiglu_fwd_st plus a rider (may be NULL), as fvqa_gemm_nt_rider: inside the launch when the kernel that takes
+ * the main problem has workgroups to spare in its last round, else as its own launch right after. The step puts the NEXT
+ * layer's adapter K/V rows here (they depend on parameters only): the W1|W3 launch of 1.8 rounds of 192-column tiles has 52
+ * workgroups without a tile in its second round, the QKV launch of 256 such tiles none. */
+int fvqa_gemm_nt_swiglu_fwd_st_rider(const void* A, const void* B13, void* st, void* z, int M, int hidden, int K, int lda,
+                                     int ldb, int dtype, const fvqa_sk_rider* rider, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 /* The QKV projection with RoPE where it is produced (bf16; reference llama/model.py:61-67 applied to wq(x), wk(x) :89-93):
  * C[M, N] = A · B^T with columns [0, rope->cols) — the q | k heads, rope->cols = 2 * n_heads * head_dim — rotated by the
  * tables (rows of head_dim / 2 floats per position, as fvqa_rope_qk takes them) of position (row % seq_len): value rounded to
@@ -147,7 +154,7 @@ int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* pla
  * un-instrumented step; a co-prime stride samples every launch position over a few steps at 1/n of that disturbance.
  * fvqa_gemm_timing_read synchronises, returns the number of launches recorded since enable and fills up to `max`
  * entries: duration (us; -2 = counted but not bracketed, -1 = event error), algorithmic FLOPs (2*M*N*K of that launch)
- * and kind = epilogue | split_k << 4 | out_is_f32 << 5 | in_is_f32 << 6; it then clears the record (max <= 0: size query
+ * and kind = epilogue | split_k << 4 | out_is_f32 << 5 | in_is_f32 << 6 | four_wave_kernel << 7; it then clears the record (max <= 0: size query
  * only, nothing cleared). enable(0) stops recording and frees the probe. Launches from any host thread are recorded (the
  * step's backward runs on the autograd thread); switch it while no launch is in flight. */
 int fvqa_gemm_timing_enable(int on);
@@ -183,6 +190,11 @@ int fvqa_swiglu_bwd(const void* dz, const void* ab, void* dab, int rows, int hid
  * kernel rotates them on the fly with the tables of fvqa_rope_qk (identical values to the separate
  * pass; llama/model.py:96); only builds for which fvqa_attn_rope_fused(dtype) == 1 accept them. */
 int fvqa_attn_rope_fused(int dtype);
+/* 1 when the step schedule computes the adapter K/V rows of layer i+1 as the rider of layer i's W1|W3 launch (and layer 0's as
+ * a launch of its own before the walk) instead of beside layer i+1's QKV projection: bf16 build with the (s, t) SwiGLU form.
+ * fvqa_swiglu_st: 1 unless FVQA_SWIGLU_AB=1 (tuning switch: a, b saved and the full SwiGLU' arithmetic in the W2^T epilogue). */
+int fvqa_kv_rider_ahead(int dtype);
+int fvqa_swiglu_st(void);
 /* 1 when the step schedule (fvqa_layers_forward / _backward) rotates q, k in the QKV projection's epilogue (fvqa_gemm_nt_rope):
  * the arena's qkv rows — the KV cache of the generation path — then hold ROTATED q, k (bf16 MFMA build; FVQA_ROPE_IN_GEMM=0
  * keeps raw q, k rotated inside the attention kernels). */

@@ -51,9 +51,10 @@ __device__ __forceinline__ void ring4_loop(f32x16 (&acc)[NBT], unsigned lds0, co
                                            const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int m0, int n0,
                                            size_t kel0, int nw, int w, int lane, int rowxor = 0) {
   if (nw <= 0) return;
-  const unsigned long long pa = (unsigned long long)(uintptr_t)A, pb = (unsigned long long)(uintptr_t)B;
-  const u32x4 rsA = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xFFFFu, (unsigned)M * (unsigned)lda * 2u, 0x00020000u};
-  const u32x4 rsB = u32x4{(unsigned)pb, (unsigned)(pb >> 32) & 0xFFFFu, (unsigned)N * (unsigned)ldb * 2u, 0x00020000u};
+  const unsigned long long pa = (unsigned long long)(uintptr_t)A & 0xFFFFFFFFFFFFull, pb = (unsigned long long)(uintptr_t)B & 0xFFFFFFFFFFFFull;
+  const unsigned long long rsAB2 = (unsigned long long)((unsigned)M * (unsigned)lda * 2u) | ((unsigned long long)((unsigned)N * (unsigned)ldb * 2u) << 32);
+  const unsigned long long str8 = (unsigned long long)(8u * (unsigned)lda * 2u) | ((unsigned long long)(8u * (unsigned)ldb * 2u) << 32);
+  const unsigned long long wl = (unsigned long long)((unsigned)w | (((unsigned)rowxor >> 3) << 8)) | ((unsigned long long)lds0 << 32);
   const int lr = lane >> 3, lc = (lane & 7) ^ lr;                       // row within a piece; swizzled 16-byte chunk
   const unsigned voffA = (unsigned)(m0 + 64 * w + lr) * (unsigned)lda * 2u + (unsigned)lc * 16u;
   const unsigned voffB = (unsigned)(n0 + lr) * (unsigned)ldb * 2u + (unsigned)lc * 16u;
@@ -61,8 +62,7 @@ __device__ __forceinline__ void ring4_loop(f32x16 (&acc)[NBT], unsigned lds0, co
   const unsigned ck0 = (unsigned)((fkc ^ fsw) << 4);
   const unsigned rdA = lds0 + (unsigned)((64 * w + frow) * 128) + ck0;
   const unsigned rdB = lds0 + (unsigned)(SA * A_STAGE) + (unsigned)(frow * 128) + ck0;
-  Ring4Asm<NBT>::run(acc, rsA, rsB, (unsigned)(kel0 * 2), 8u * (unsigned)lda * 2u, 8u * (unsigned)ldb * 2u, (unsigned)nw, lds0,
-                     (unsigned)w, (unsigned)rowxor >> 3, voffA, voffB, rdA, rdB);
+  Ring4Asm<NBT>::run(acc, pa, pb, rsAB2, str8, wl, (unsigned)(kel0 * 2), (unsigned)nw, voffA, voffB, rdA, rdB);
 }
 
 }  // namespace fvqa_ring4

@@ -11,16 +11,18 @@ batch 8 per GPU, max_feats 10, VQA loss only. N>1 = the same per-GPU work on eve
 scaling), one all-reduce(mean) of 4.5 M fp32 gradients per step.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     — the dominant kernel (persistent bf16 projection GEMM gemm_sk_256, every launch of
-                 every instantiation): algorithmic FLOPs / launch time against the 2.5 PFLOP/s dense
-                 bf16 MFMA peak. Launch times come from HIP events the library records on the launch
-                 stream around every launch in an INSTRUMENTED repeat of the same steps under the same
-                 native schedule (`frac_probe`, with that pass's own ms_per_step beside it); `frac` /
-                 `achieved` restate them for the TIMED region: the non-GEMM time of a step (instrumented
-                 step - probe GEMM time - event overhead) is subtracted from the timed step;
+  roofline     — the dominant kernel family (the bf16 projection GEMMs: the 4-wave whole-tile kernel gemm4w_k
+                 and the split-K kernel gemm_sk_256, every launch of every instantiation): algorithmic
+                 FLOPs / launch time against the 2.5 PFLOP/s dense bf16 MFMA peak. Launch times come from
+                 HIP events the library records on the launch stream around every 17th launch in an
+                 INSTRUMENTED repeat of the same steps under the same native schedule (that pass's own
+                 ms_per_step is in the line; a pass with every launch bracketed is reported as
+                 `dense_probe`); `alg_bytes_per_launch` (operands + outputs of each launch, from its shape)
+                 stands beside `traffic` (fabric bytes per launch from the committed PMC passes);
   step_roofline— algorithmic FLOPs of the whole step (SURVEY §8d formula) / step time;
-  cpu_baseline — the CPU oracle (oracle/ref_cpu.py) timed on this host's cores: full-depth steps on
-                 B=2 samples of the same workload, one warm-up + the faster of two (rank 0, N=1 only).
+  cpu_baseline — the CPU oracle (oracle/ref_cpu.py) timed on this host's cores on BASELINE configs[0]:
+                 full-depth 7B, B=2, all three losses, forward+backward+AdamW, one warm-up + up to three timed
+                 steps within a host-time budget (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -55,6 +57,28 @@ def step_flops(D, H, L, Hf, V, N, S, A, F, tasks):
     return tot
 
 
+def launch_alg_bytes(kind, flops, R, D, Hf, V):
+    """Algorithmic bytes of one projection launch of the step, identified by its epilogue kind and FLOP count: operands
+    read once + outputs written once (bf16; fp32 logits), epilogue operands included (residual rows; the saved SwiGLU
+    factors read by the W2^T launch; z next to (s, t) written by the W1|W3 launch). None for a shape it does not know."""
+    shapes = {  # (epilogue, out is fp32) -> [(N, K)]
+        (7, False): [(3 * D, D)], (0, False): [(D, D), (D, 3 * D), (D, 2 * Hf), (D, V)], (1, False): [(D, D), (D, Hf)],
+        (5, False): [(2 * Hf, D)], (4, False): [(2 * Hf, D)], (6, False): [(Hf, D)], (3, False): [(Hf, D)],
+        (0, True): [(V, D)]}
+    epi, f32 = kind & 15, bool(kind & 32)
+    for (N, K) in shapes.get((epi, f32), []):
+        if abs(2.0 * R * N * K - flops) < 1e-6 * flops:
+            b = 2.0 * R * K + 2.0 * N * K + (4.0 if f32 else 2.0) * R * N
+            if epi == 1:
+                b += 2.0 * R * N                        # residual rows
+            if epi in (4, 5):
+                b += 2.0 * R * N / 2                    # z
+            if epi in (3, 6):
+                b += 2.0 * R * 2 * N + 2.0 * R * N      # reads (s, t) rows of 2N, writes d(a|b) rows of 2N instead of N
+            return b
+    return None
+
+
 def _cpu_extrapolated(seq_len, max_feats):
     """Fallback: oracle fwd+bwd at 7B width for 1 and 2 layers, B=2, VQA only; per-layer and fixed cost separated and
     scaled to 32 layers."""
@@ -85,35 +109,55 @@ def _cpu_extrapolated(seq_len, max_feats):
                       f"({times[1]:.2f}s, {times[2]:.2f}s) and scaled to 32 layers + head ({full:.1f}s/step)"}
 
 
-def cpu_baseline_leg(seq_len, max_feats):
-    """The CPU oracle (oracle/ref_cpu.py, fp32) timed on this host's cores on a bounded sample of the workload: ONE full
-    step (forward + backward, all 32 layers of the 7B, VQA loss) on B=2 samples of the same sequence length — the
-    reference's own batch for its CPU-runnable configuration. The 27 GB of closed-form fp32 weights are generated on the
-    GPU tensor by tensor and copied to the host (the generator is the same counter hash on either device). Falls back
-    to the 1- and 2-layer extrapolation if the full-depth model cannot be built (host memory)."""
+def cpu_baseline_leg(seq_len, max_feats, budget_s=240.0):
+    """The CPU oracle (oracle/ref_cpu.py, fp32) timed on this host's cores on SURVEY §8d's sample: BASELINE configs[0] (C1)
+    — the full 32-layer 7B, B = 2 samples of the same sequence length, ALL THREE flipped losses (--vaq --qav) — forward +
+    backward + AdamW(0.9, 0.95) on the 4.5 M trainables, one warm-up step (first touch of 27 GB of weights) and up to three
+    timed ones within `budget_s` of host time (a slow host stops earlier; how many were timed is stated). The closed-form
+    fp32 weights are generated on the GPU tensor by tensor and copied over (same counter hash on either device). `value`
+    is samples/s of that workload (3 streams per sample); `per_stream_value` restates it per (sample, stream) pair, the
+    unit in which it compares with the VQA-only GPU line. Falls back to the 1- / 2-layer extrapolation if the full-depth
+    model cannot be built (host memory)."""
     from fvqa import synth
     from oracle import ref_cpu
     try:
-        cfg = synth.preset("7b", max_seq_len=seq_len, max_feats=max_feats, batch_size=2)
+        cfg = synth.preset("7b", max_seq_len=seq_len, max_feats=max_feats, batch_size=2, vaq=True, qav=True)
         dev = "cuda" if torch.cuda.is_available() else "cpu"
         sd = {n: synth.make_tensor(cfg, n, shape, kind, device=dev).cpu() for n, shape, kind in synth.state_spec(cfg)}
         model = ref_cpu.RefModel(cfg, sd, dtype=torch.float32)
         del sd
         batch = synth.make_batch(cfg, seed=0)
+        names = [n for n in model.sd if synth.is_trainable(n)]
+        params = [torch.nn.Parameter(model.sd[n]) for n in names]       # AdamW updates the oracle's tensors in place
+        for n, p_ in zip(names, params):
+            model.sd[n] = p_.data
+        opt = torch.optim.AdamW(params, lr=9e-2 * 2 / 256, betas=(0.9, 0.95), weight_decay=0.14)
+
+        def one_step():
+            out = model.step(batch)
+            for n, p_ in zip(names, params):
+                p_.grad = out["grads"][n]
+            opt.step()
+
+        t_start = time.perf_counter()
         times = []
-        for _ in range(3):                         # one warm-up (first touch of 27 GB of weights) + two timed
+        for i in range(4):                         # warm-up + up to three timed steps
             t0 = time.perf_counter()
-            model.step(batch)
+            one_step()
             times.append(time.perf_counter() - t0)
-            if len(times) == 1 and times[0] > 75.0:
-                break                              # a slow host: keep the default run within minutes
-        dt = min(times[1:]) if len(times) > 1 else times[0]
+            if i >= 1 and (time.perf_counter() - t_start) + times[-1] > budget_s:
+                break
+            if i == 0 and times[0] > 0.45 * budget_s:
+                break                              # a slow host: the warm-up step is the measurement
+        timed = times[1:] if len(times) > 1 else times
+        dt = min(timed)
         del model
-        return {"value": 2.0 / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                "method": "measured_full_depth",
-                "sample": f"oracle/ref_cpu.py fp32, full LLaMA-7B (32 layers), forward+backward steps on B=2 "
-                          f"samples, S={seq_len}, VQA loss: warm-up {times[0]:.1f}s, timed "
-                          f"{', '.join(f'{t:.1f}s' for t in times[1:]) or 'none (warm-up used)'}; value = 2 / {dt:.1f}s"}
+        return {"value": 2.0 / dt, "unit": "samples/s", "per_stream_value": 6.0 / dt, "cores": torch.get_num_threads(),
+                "cpus": os.cpu_count(), "kind": "port", "method": "measured_full_depth",
+                "sample": f"oracle/ref_cpu.py fp32, BASELINE configs[0]: full LLaMA-7B (32 layers), B=2 samples, S={seq_len}, "
+                          f"losses vqa+vaq+qav, forward+backward+AdamW steps: warm-up {times[0]:.1f}s, timed "
+                          f"{', '.join(f'{t:.1f}s' for t in times[1:]) or 'none (warm-up used)'}; value = 2 samples / "
+                          f"{dt:.1f}s (fastest timed step), {torch.get_num_threads()} torch threads on {os.cpu_count()} CPUs"}
     except (RuntimeError, MemoryError) as e:
         out = _cpu_extrapolated(seq_len, max_feats)
         out["fallback_reason"] = repr(e)[:200]
@@ -212,10 +256,19 @@ def main():
     local = local % max(1, torch.cuda.device_count())       # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    diag = None
     if world > 1:
         # RCCL over xGMI; FVQA_DIST_BACKEND=gloo only for single-GPU rehearsals of the N>1 control flow
         dist.init_process_group(os.environ.get("FVQA_DIST_BACKEND", "nccl"), init_method="env://",
                                 world_size=world, rank=rank)
+        # start-up self-diagnosis: RCCL world == --gpus, one rank per whole MI355X (256 CUs, no compute partition), host
+        # threads pinned per rank; raises on every rank with the list of problems (fvqa/rankcheck.py)
+        sys.path.insert(0, os.path.join(ROOT, "flipped-vqa_amd"))
+        from fvqa import rankcheck
+        host_threads = rankcheck.pin_host_threads(world)
+        diag = rankcheck.check_ranks(a.gpus, rank, int(os.environ.get("LOCAL_RANK", "0")), local,
+                                     rehearsal=os.environ.get("FVQA_BENCH_REHEARSAL") == "1")
+        diag["host_threads_per_rank"] = host_threads
 
     import util.misc as misc
     from fvqa import ops, synth
@@ -319,9 +372,14 @@ def main():
         ev, net.comm_events = net.comm_events, None
         comm_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
         t = torch.tensor([dt, sum(comm_ms) / max(1, len(comm_ms))], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(per_rank, t)                      # every rank's own clock and all-reduce time: who is the slow one
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
+        rank_ms = [float(x[0].item()) / a.steps * 1e3 for x in per_rank]
         comm = {"allreduce_ms": float(t[1].item()), "allreduce_calls_per_step": len(comm_ms) / a.steps,
+                "ms_per_step_per_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+                "allreduce_ms_per_rank": [float(x[1].item()) for x in per_rank],
                 "allreduce_bytes": int(model.flat_params().flat_grad.numel() * 4),
                 "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
                 "note": "max over ranks of the mean device time between the events bracketing all_reduce(SUM) of the "
@@ -375,6 +433,9 @@ def main():
             return ("f32" if kind & 64 else "bf16") + "_" + ("f32" if kind & 32 else "bf16") + "_" + \
                 epi_name.get(kind & 15, str(kind & 15)) + ("_splitk" if kind & 16 else "") + ("_4w" if kind & 128 else "")
 
+        R_ = a.batch_size * a.seq_len * (1 + int(a.vaq) + int(a.qav))
+        Hf_ = model.layers[0].feed_forward.w1.weight.shape[0]
+
         def summarise(rec):
             """per (kind, FLOPs) = per shape of an instantiation: launches per step, mean duration of the bracketed ones"""
             sh = {}
@@ -395,10 +456,14 @@ def main():
                 tot_f += per_step * fl
                 n_launch += cnt
                 n_timed += nt
-                p_ = per.setdefault(name_of(kind), [0.0, 0.0, 0.0])
+                p_ = per.setdefault(name_of(kind), [0.0, 0.0, 0.0, 0.0, 0.0])
                 p_[0] += per_step
                 p_[1] += per_step * mean_us
                 p_[2] += per_step * fl
+                ab = launch_alg_bytes(kind, fl, R_, p.dim, Hf_, model.vocab_size)
+                if ab is not None:
+                    p_[3] += per_step * ab
+                    p_[4] += per_step
             return per, tot_ms, tot_f, n_launch, n_timed, missing
 
         per, gemm_ms, flops_step, n_launch, n_timed, missing = summarise(rec_sparse)
@@ -415,18 +480,19 @@ def main():
             # fabric-side bytes per launch from the rocprofv3 --pmc passes of THIS command (tools/pmc_summary.py:
             # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), valid only for the kernel sources they were collected with
             traffic, tsrc = None, None
-            tj = os.path.join(ROOT, "profiles", "r03_pmc_mfma_lds.json")
-            if a.dtype == "bf16" and a.model == "7B" and not (a.vaq or a.qav) and a.seq_len == 128 and os.path.exists(tj):
+            tj = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_mfma_lds.json", "r03_pmc_mfma_lds.json"))
+                       if os.path.exists(f)), None)
+            if a.dtype == "bf16" and a.model == "7B" and not (a.vaq or a.qav) and a.seq_len == 128 and tj:
                 pm = json.load(open(tj))
                 from fvqa import build as fbuild
                 if pm.get("source_hash") == fbuild.source_hash():
                     w_ = [(v["launches_sampled"], v["hbm_bytes_per_launch"]) for k, v in pm.get("kernels", {}).items()
-                          if k.startswith("gemm_sk_256") and "hbm_bytes_per_launch" in v]
+                          if (k.startswith("gemm_sk_256") or "gemm4w_k" in k) and "hbm_bytes_per_launch" in v]
                     if w_:
                         traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
-                        tsrc = f"profiles/r03_pmc_mfma_lds.json (kernel sources {pm['source_hash'][:12]}, same workload)"
+                        tsrc = f"profiles/{os.path.basename(tj)} (kernel sources {pm['source_hash'][:12]}, same workload)"
             roof = {"bound": "mfma",
-                    "kernel": "gemm_sk_256 (every launch of every instantiation in the step: persistent 256x256-tile LDS-DMA ring kernel, split-K reduced in the launch)",
+                    "kernel": "projection GEMMs of the step, every launch of every instantiation: gemm4w_k (4-wave whole-tile kernel, one wave per SIMD, tile width per problem: *_4w) and gemm_sk_256 (persistent 256x256-tile split-K kernel, reduced in the launch: *_splitk)",
                     "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_source": tsrc,
                     "method": f"HIP events around every {stride_used}th launch in a repeat of the timed steps "
@@ -441,8 +507,13 @@ def main():
                     "dense_probe": {"frac": (flops_dense / (gemm_ms_dense * 1e-3) / peak) if gemm_ms_dense > 0 else None,
                                     "gemm_ms_per_step": gemm_ms_dense, "ms_per_step_this_pass": ms_dense,
                                     "note": "every launch bracketed (rounds 1-2 method): lighter duty cycle, reads high"},
+                    "alg_bytes_per_launch": (sum(v[3] for v in per.values()) / max(1e-9, sum(v[4] for v in per.values()))
+                                             if any(v[4] for v in per.values()) else None),
                     "per_instantiation": {k: {"launches_per_step": v[0], "avg_launch_us": v[1] / v[0],
-                                              "TFLOP/s": v[2] / v[1] / 1e6} for k, v in per.items()}}
+                                              "TFLOP/s": v[2] / v[1] / 1e6,
+                                              "alg_bytes_per_launch": (v[3] / v[4]) if v[4] else None,
+                                              "alg_GB/s": (v[3] / v[4]) / (v[1] / v[0]) / 1e3 if v[4] else None}
+                                          for k, v in per.items()}}
             # the probe must account for the step it ran in: GEMM + a plausible rest
             if not (0.0 < non_gemm_ms < 0.5 * ms_pass):
                 roof["inconsistent"] = "probe GEMM time + event pairs does not fit the pass's own step time"
@@ -473,6 +544,10 @@ def main():
         }
         if comm is not None:
             out["comm"] = comm
+        if diag is not None:
+            out["ranks"] = {"host_threads_per_rank": diag["host_threads_per_rank"], "problems": diag["problems"],
+                            "devices": [{k: r.get(k) for k in ("rank", "host", "device_id", "cu_count", "gcn_arch", "hbm_gib")}
+                                        for r in diag["reports"]]}
         if a.n_layers:
             out["invalid"] = "reduced depth (debug run)"
         if gemm_error is not None:

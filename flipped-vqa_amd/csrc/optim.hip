@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void unscale_sq_k(float* __restrict__ grad, co
 __global__ __launch_bounds__(256) void norm_finish_k(const float* __restrict__ part, int n_seg,
                                                      float* __restrict__ seg_sq, float* __restrict__ found_inf,
                                                      float* __restrict__ total_norm,
-                                                     const unsigned long long* __restrict__ gemm_err) {
+                                                     const unsigned long long* __restrict__ gemm_err,
+                                                     const float* __restrict__ err_lane) {
   __shared__ float red[4];
   float tot = 0.f, bad = 0.f;
   for (int s = threadIdx.x; s < n_seg; s += 256) {
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void norm_finish_k(const float* __restrict__ p
     float f = (bad > 0.f || !isfinite(tot)) ? 1.f : 0.f;
     if (gemm_err != nullptr &&
         __hip_atomic_load(gemm_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) f = 2.f;
+    if (err_lane != nullptr && err_lane[0] != 0.f) f = 2.f;     // some rank's error word, summed in with the gradients
     found_inf[0] = f;
   }
 }
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const floa
 __global__ void scaler_update_k(float* __restrict__ step, float* __restrict__ scale, float* __restrict__ tracker,
                                 const float* __restrict__ found_inf, float growth, float backoff, float interval) {
   if (threadIdx.x || blockIdx.x) return;
+  if (found_inf[0] == 2.f) return;         // a timed-out GEMM exchange is not an overflow: the scale keeps its history
   if (found_inf[0] != 0.f) {
     if (scale) { scale[0] *= backoff; tracker[0] = 0.f; }
   } else {
@@ -121,8 +124,9 @@ __global__ void scaler_update_k(float* __restrict__ step, float* __restrict__ sc
 extern "C" size_t fvqa_grad_norm_workspace(int n_seg) { return (size_t)(n_seg > 0 ? n_seg : 0) * NB * 2 * sizeof(float); }
 
 extern "C" int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n_seg, const float* scale,
-                                      float grad_div, const void* gemm_err, float* seg_sq, float* found_inf,
-                                      float* total_norm, void* workspace, size_t workspace_bytes, void* stream) {
+                                      float grad_div, const void* gemm_err, const float* err_lane, float* seg_sq,
+                                      float* found_inf, float* total_norm, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
   if (!grad || !seg_off || !scale || !seg_sq || !found_inf || !total_norm || !workspace) return FVQA_EINVAL;
   if (!(grad_div >= 1.f) || ((uintptr_t)gemm_err & 7)) return FVQA_EINVAL;
   if (n_seg <= 0 || n_seg > 65535) return FVQA_ESHAPE;
@@ -130,7 +134,7 @@ extern "C" int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(unscale_sq_k, dim3(NB, n_seg), dim3(256), 0, st, grad, seg_off, scale, grad_div, (float*)workspace);
   hipLaunchKernelGGL(norm_finish_k, dim3(1), dim3(256), 0, st, (const float*)workspace, n_seg, seg_sq, found_inf,
-                     total_norm, (const unsigned long long*)gemm_err);
+                     total_norm, (const unsigned long long*)gemm_err, err_lane);
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
@@ -157,5 +161,4 @@ extern "C" int fvqa_scaler_update(float* step, float* scale, float* growth_track
   return FVQA_OK;
 }
 
-extern "C" int fvqa_version(void) { return 12; }
 extern "C" const char* fvqa_arch(void) { return "gfx950"; }

@@ -19,6 +19,7 @@ _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 # name -> (restype, argtypes); must list every entry point of include/fvqa.h
 SIGNATURES = {
     "fvqa_version": (_i, []),
+    "fvqa_source_hash": (C.c_char_p, []),
     "fvqa_arch": (C.c_char_p, []),
     "fvqa_gemm_nt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "fvqa_gemm_workspace": (_sz, [_i, _i, _i, _i]),
@@ -54,7 +55,7 @@ SIGNATURES = {
     "fvqa_qav_head_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "fvqa_qav_head_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
     "fvqa_grad_norm_workspace": (_sz, [_i]),
-    "fvqa_grad_unscale_norm": (_i, [_p, _p, _i, _p, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "fvqa_grad_unscale_norm": (_i, [_p, _p, _i, _p, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "fvqa_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p]),
     "fvqa_scaler_update": (_i, [_p, _p, _p, _p, _f, _f, _i, _p]),
     "fvqa_cast_rows": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -131,8 +132,23 @@ def load() -> C.CDLL:
     v = lib.fvqa_version()
     if v != ABI_VERSION:
         raise FvqaLibraryError(f"{path}: ABI version {v}, host expects {ABI_VERSION}")
+    check_source_hash(lib, path)
     _LIB = lib
     return lib
+
+
+def check_source_hash(lib, path: str) -> None:
+    """The library is git-ignored and travels as a binary: refuse one that was built from other kernel sources than the ones
+    next to it (a stale build with the same ABI number would otherwise be loaded — and tested — silently)."""
+    from . import build
+    if not os.path.isdir(build.CSRC):
+        return                                   # a deployed library without its sources: nothing to compare with
+    have = (lib.fvqa_source_hash() or b"").decode()
+    want = build.source_hash()
+    if have != want:
+        raise FvqaLibraryError(
+            f"{path} was built from kernel sources {have[:12] or '?'}, the sources here are {want[:12]}: stale binary — "
+            "rebuild it (`python -m fvqa.build`, or __graft_entry__.build())")
 
 
 def check(rc: int, what: str) -> None:

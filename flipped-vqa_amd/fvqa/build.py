@@ -51,18 +51,29 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST_BUILD = {"compiled": 0, "linked": False}        # what the last build() call did (tests, __graft_entry__.build)
+
+
 def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=()) -> str:
-    """defines: extra -D macros (tuning builds write to a different `out`, always from scratch)."""
+    """defines: extra -D macros (tuning builds write to a different `out`, always from scratch).
+    Every build compiles the hash of the kernel sources into the library (csrc/version.hip, -DFVQA_SOURCE_HASH), which
+    fvqa/_lib.py checks at load time: an old binary next to newer sources does not load."""
     if defines:
         return _build_variant(out, defines, verbose)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
+    shash = source_hash()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "fvqa.h"))
     jobs, objs = [], []
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
+        if os.path.basename(src) == "version.hip":           # carries the source hash: rebuilt whenever the hash moves
+            stamp = obj + ".hash"
+            if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != shash:
+                jobs.append([hipcc, *FLAGS, f'-DFVQA_SOURCE_HASH="{shash}"', "-c", src, "-o", obj])
+            continue
         if force or _stale(obj, [src] + headers):
             jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
 
@@ -77,14 +88,21 @@ def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=())
 
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
+    open(os.path.join(OBJDIR, "version.o.hash"), "w").write(shash)
+    link = bool(jobs) or force or _stale(LIB, objs)
+    if link:
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+    LAST_BUILD.update(compiled=len(jobs), linked=link)
+    if verbose:
+        print(f"[fvqa.build] {len(jobs)} of {len(objs)} objects compiled, library {'linked' if link else 'up to date'}, "
+              f"sources {shash[:12]}", flush=True)
     return LIB
 
 
 def _build_variant(out, defines, verbose):
     hipcc = _hipcc()
-    cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-shared", "-o", out, *sources()]
+    cmd = [hipcc, *FLAGS, f'-DFVQA_SOURCE_HASH="{source_hash()}"', *[f"-D{d}" for d in defines], "-shared", "-o", out,
+           *sources()]
     if verbose:
         print("[fvqa.build]", " ".join(cmd[-8:]), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

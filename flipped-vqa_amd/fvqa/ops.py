@@ -609,10 +609,12 @@ def grad_norm_workspace(n_seg: int) -> int:
 
 
 def grad_unscale_norm(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace, grad_div: float = 1.0,
-                      gemm_err: Optional[torch.Tensor] = None):
+                      gemm_err: Optional[torch.Tensor] = None, err_lane: Optional[torch.Tensor] = None):
     """grad_div: replicas summed into `grad` (the data-parallel mean is applied here); gemm_err: the 8-byte error word of
-    the GEMM workspace (gemm_error_word) — non-zero makes found_inf 2 and the optimizer step a no-op."""
-    _dev(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace, gemm_err)
+    the GEMM workspace (gemm_error_word) — non-zero makes found_inf 2 and the optimizer step a no-op; err_lane: the fp32
+    element data-parallel ranks all-reduce with the gradients (FlatParams.err_lane) — non-zero does the same on EVERY rank."""
+    _dev(grad, seg_off, scale, seg_sq, found_inf, total_norm, workspace, gemm_err, err_lane)
+    _need(err_lane is None or (err_lane.dtype == torch.float32 and err_lane.numel() >= 1), "grad_unscale_norm: err_lane")
     _need(grad_div >= 1.0, "grad_unscale_norm: grad_div")
     _need(gemm_err is None or gemm_err.numel() * gemm_err.element_size() >= 8, "grad_unscale_norm: gemm_err")
     n_seg = seg_off.numel() - 1
@@ -620,7 +622,7 @@ def grad_unscale_norm(grad, seg_off, scale, seg_sq, found_inf, total_norm, works
     _need(seg_sq.numel() >= n_seg and seg_sq.dtype == torch.float32, "grad_unscale_norm: seg_sq")
     wbytes = workspace.numel() * workspace.element_size()
     rc = _lib.load().fvqa_grad_unscale_norm(_ptr(grad), _ptr(seg_off), n_seg, _ptr(scale), float(grad_div),
-                                            _ptr(gemm_err), _ptr(seg_sq), _ptr(found_inf), _ptr(total_norm),
+                                            _ptr(gemm_err), _ptr(err_lane), _ptr(seg_sq), _ptr(found_inf), _ptr(total_norm),
                                             _ptr(workspace), wbytes, _stream())
     _lib.check(rc, "fvqa_grad_unscale_norm")
 

@@ -93,12 +93,32 @@ class DataParallel(torch.nn.Module):
         loss scaler's unscale kernel divides (fvqa_grad_unscale_norm grad_div). With `comm_events` set to a list,
         each call appends a (start, end) event pair recorded on the current stream (bench.py: allreduce_ms)."""
         flat = self.module.flat_params()
+        # the error lane behind the gradients rides in the same collective: 1 on a rank whose persistent-GEMM error word is
+        # raised (a timed-out split-K exchange), so that every rank sees a non-zero sum, skips this step and stops with the
+        # others instead of applying an update the faulty rank does not apply
+        buf = getattr(flat, "grad_store", None)
+        if buf is None:
+            buf = flat.flat_grad
+        else:
+            word = self.error_word()
+            if word is not None:
+                flat.err_lane.copy_(word.view(torch.int64) != 0)
+            else:
+                flat.err_lane.zero_()
         ev = self.comm_events
         if ev is not None and flat.flat_grad.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            n = allreduce_sum_(flat.flat_grad, self.group)
+            n = allreduce_sum_(buf, self.group)
             e1.record()
             ev.append((e0, e1))
             return n
-        return allreduce_sum_(flat.flat_grad, self.group)
+        return allreduce_sum_(buf, self.group)
+
+    def error_word(self):
+        """8-byte device view of this rank's persistent-GEMM error word (None before the first such launch)."""
+        fg = self.module.flat_params().flat_grad
+        if not fg.is_cuda:
+            return None
+        from . import ops
+        return ops.gemm_error_word(fg.device)

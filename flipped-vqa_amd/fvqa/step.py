@@ -439,7 +439,12 @@ class FlatParams:
         total = sum(sizes) + gate_elems
         dev = named[self.names[0]].device
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        # the gradient buffer and, behind it, the ERROR LANE: one fp32 (padded to 16 bytes) that data-parallel ranks all-reduce
+        # in the same collective as the gradients — a rank whose persistent-GEMM error word is raised sets it to 1, the sum is
+        # non-zero on every rank, and all replicas skip the step together (fvqa_grad_unscale_norm err_lane)
+        self.grad_store = torch.zeros(total + 4, dtype=torch.float32, device=dev)
+        self.flat_grad = self.grad_store[:total]
+        self.err_lane = self.grad_store[total:total + 1]
         self.offsets = {}
         off = 0
         for n, sz in zip(self.names, sizes):

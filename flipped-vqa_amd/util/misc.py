@@ -186,7 +186,16 @@ def init_distributed_mode(args):
     print(f"| distributed init (rank {args.rank}): {args.dist_url}, gpu {args.gpu}", flush=True)
     dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size,
                             rank=args.rank)
+    # start-up self-diagnosis (fvqa/rankcheck.py): one rank per whole MI355X, host threads pinned per rank — a wrong
+    # LOCAL_RANK -> device map or a partitioned device is reported here, by every rank, before the first step
+    from fvqa import rankcheck
+    args.host_threads = rankcheck.pin_host_threads(args.world_size, getattr(args, "num_workers", 0))
+    diag = rankcheck.check_ranks(args.world_size, args.rank, args.gpu, args.gpu,
+                                 rehearsal=os.environ.get("FVQA_DIST_REHEARSAL") == "1")
     setup_for_distributed(args.rank == 0)
+    print(f"| {len(diag['reports'])} ranks, one per device: " +
+          ", ".join(f"r{r['rank']}@{r['host']}:{r.get('device_id') or r.get('device_index')}({r.get('cu_count')} CUs)"
+                    for r in diag["reports"]) + f"; {args.host_threads} host threads per rank", flush=True)
 
 
 # ------------------------------------------------------------------------------ loss scaler
@@ -246,8 +255,10 @@ class NativeScalerWithGradNormCount:
             self._seg_sq = torch.empty(n_seg, dtype=torch.float32, device=self._dev)
             self._ws = torch.empty(ops.grad_norm_workspace(n_seg), dtype=torch.uint8, device=self._dev)
         # a timed-out split-K exchange (error word of the stream's GEMM workspace) makes found_inf 2: skipped like an overflow
+        # ... on THIS rank through the error word, on any rank through the error lane summed in with the gradients
+        lane = getattr(flat, "err_lane", None) if optimizer.grad_sync is not None else None
         ops.grad_unscale_norm(flat.flat_grad, flat.seg_off, self._scale, self._seg_sq, self._found, self._norm,
-                              self._ws, grad_div=float(div), gemm_err=ops.gemm_error_word(self._dev))
+                              self._ws, grad_div=float(div), gemm_err=ops.gemm_error_word(self._dev), err_lane=lane)
         if clip_grad is not None:
             flat.flat_grad.mul_(torch.clamp(clip_grad / (self._norm + 1e-6), max=1.0))
         optimizer.step(found_inf=self._found)

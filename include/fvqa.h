@@ -53,6 +53,9 @@ extern "C" {
  * same hidden unit in the same lane, and SwiGLU becomes that GEMM's epilogue. hidden % 16 == 0. */
 
 int fvqa_version(void);      /* ABI version, bumped on any signature change */
+/* sha256 (hex) of the kernel sources (csrc/ *.hip, *.h, include/fvqa.h) this library was compiled from, "unknown" for a build
+ * outside fvqa/build.py. The host binding compares it with the sources next to the library and refuses a stale binary. */
+const char* fvqa_source_hash(void);
 const char* fvqa_arch(void); /* "gfx950"                                     */
 
 /* ---- dense projections: F.linear with frozen weights ---------------------------------
@@ -298,11 +301,15 @@ int fvqa_qav_head_bwd(const void* xn, const float* vf_raw, const int64_t* labels
  * grad_div >= 1: the number of data-parallel replicas whose gradients were SUMMED into `grad` by the all-reduce (DDP's
  * mean of train.py:115-117 without a pass of its own; 1 on a single GPU).
  * gemm_err (may be NULL): device address of a persistent-GEMM workspace's error word (fvqa_gemm_workspace); when it is
- * non-zero the step is skipped like an overflow and found_inf[0] = 2. */
+ * non-zero the step is skipped like an overflow and found_inf[0] = 2.
+ * err_lane (may be NULL): one fp32 that data-parallel ranks all-reduce TOGETHER with the gradients (the element behind the
+ * flat gradient buffer, set to 1 by a rank whose error word is raised): non-zero on every rank as soon as one rank's
+ * exchange timed out, so all replicas skip the same step (found_inf[0] = 2) and stop together.
+ * fvqa_scaler_update leaves the loss scale and its growth tracker untouched when found_inf[0] == 2. */
 size_t fvqa_grad_norm_workspace(int n_seg);
 int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n_seg, const float* scale, float grad_div,
-                           const void* gemm_err, float* seg_sq, float* found_inf, float* total_norm,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           const void* gemm_err, const float* err_lane, float* seg_sq, float* found_inf,
+                           float* total_norm, void* workspace, size_t workspace_bytes, void* stream);
 /* AdamW (decoupled weight decay, bias correction with t = step[0]+1), skipped entirely when
  * found_inf[0] != 0 (GradScaler.step semantics). found_inf may be NULL. */
 int fvqa_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE — generates tests/golden/eval_tiny.npz (and, run as `gen_golden_eval.py 7b_l2`, eval_7b_l2.npz) by running the REFERENCE's generation/eval path
+"""TEST INFRASTRUCTURE — generates tests/golden/eval_tiny.npz (run as `gen_golden_eval.py 7b_l2`: eval_7b_l2.npz; with a second
+argument `peaked`: eval_<preset>_peaked.npz, from SynthConfig.peaked weights — LM head tied to the token embeddings, so every
+greedy step's top-2 margin is a large fraction of the logit range and the bf16 build's token ids are pinned too) by running the
+REFERENCE's generation/eval path
 (llama/model.py:367-546 `Transformer.inference`) in this container: fp32-shim reference model with closed-form
 weights (as oracle/gen_golden.py), validation batches built by the reference's own NExT-QA reader + prompt
 templates on the synthetic table of oracle/gen_golden_loader.py (regex stand-in vocabulary, oracle/fake_sp.py).
@@ -56,7 +59,8 @@ def main():
     # the reference model (tiny width — or, with argument "7b_l2", 7B width two layers deep —, full vocabulary so that the
     # prompt ids are valid)
     pname = sys.argv[1] if len(sys.argv) > 1 else "tiny"
-    cfg = synth.preset(pname, vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4)
+    peaked = len(sys.argv) > 2 and sys.argv[2] == "peaked"
+    cfg = synth.preset(pname, vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4, peaked=peaked)
     model, margs = G.build_reference(M, cfg)
     margs.is_generation_task = True
     model.eval()
@@ -79,6 +83,21 @@ def main():
         return orig_filter(vqa_ids, mask)
 
     model.filter_and_process_output_tokens = spy_filter
+    # per greedy step: the top-2 margin of the logits the step takes its argmax from, relative to their range (a record of
+    # how decided the reference's choices are; tests read it to decide whether a bf16 build can be held to the ids)
+    margins = []
+    orig_output = model.output.forward
+
+    def spy_output(x):
+        y = orig_output(x)
+        z = y.detach().float()
+        if z.dim() == 3:
+            z = z.reshape(-1, z.shape[-1])
+        top2 = z.topk(2, dim=-1).values
+        margins.append(((top2[:, 0] - top2[:, 1]) / (z.max(dim=-1).values - z.min(dim=-1).values).clamp_min(1e-30)).min().item())
+        return y
+
+    model.output.forward = spy_output
     # the reference writes the generated tokens into the batch's own tensor (vqa_id is a view of it): keep a copy
     original = {"text_id_vqa": batch["text_id"]["vqa"].clone(), "label_vqa": batch["label"]["vqa"].clone()}
     with torch.no_grad():
@@ -88,8 +107,8 @@ def main():
            "prefix_vqa": np.array(batch["prefix_index"]["vqa"], dtype=np.int64),
            "vstart_vqa": np.array(batch["video_start"]["vqa"], dtype=np.int64),
            "answer": batch["answer"].numpy(), "video": batch["video"].numpy(),
-           "qtype": batch["qtype"].numpy()}
-    path = os.path.join(ROOT, "tests", "golden", f"eval_{pname}.npz")
+           "qtype": batch["qtype"].numpy(), "min_margin_per_call": np.array(margins, dtype=np.float32)}
+    path = os.path.join(ROOT, "tests", "golden", f"eval_{pname}{'_peaked' if peaked else ''}.npz")
     np.savez_compressed(path, **out)
     print("best", out["best"], "answers", out["answer"], "->", path, os.path.getsize(path) // 1024, "KiB")
     print("generated (first sample):", out["ids_after"][0, out["prefix_vqa"][0] - 2: out["prefix_vqa"][0] + 8])

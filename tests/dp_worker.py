@@ -13,7 +13,8 @@ os.environ.setdefault("FVQA_SYNTHETIC_TOKENIZER", "1")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-N_STEPS, INF_STEP, INF_RANK = 4, 1, 1
+N_STEPS, INF_STEP, INF_RANK = 5, 1, 1
+ERR_STEP, ERR_RANK = 3, 0          # a timed-out split-K exchange (persistent-GEMM error word) on ONE rank
 
 
 def batch_seed(rank, world, i):
@@ -79,8 +80,19 @@ def main():
         return rccl_one_rank(sys.argv[3], sys.argv[4])
     rank, world, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a box with a device per rank runs the real thing — one rank per GPU, `nccl` (= RCCL) —, a one-GPU box the rehearsal:
+    # both ranks on device 0 over gloo (the tiny fp32 model never launches the persistent split-K kernel, which needs a
+    # device to itself, so the two processes may share it)
+    multi = torch.cuda.device_count() >= world and os.environ.get("FVQA_DP_TEST_BACKEND", "auto") != "gloo"
+    device_index = rank if multi else 0
+    torch.cuda.set_device(device_index)
+    if multi:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fvqa import rankcheck
+    diag = rankcheck.check_ranks(world, rank, rank, device_index, rehearsal=not multi, strict=True)
     import util.misc as misc
     from fvqa import synth
     from fvqa.optim import FusedAdamW, param_groups_weight_decay
@@ -88,19 +100,24 @@ def main():
     from tests.gpu_util import build_model
 
     cfg = synth.preset("tiny", vaq=True, qav=True)
-    model, args = build_model(cfg, torch.float32)
+    model, args = build_model(cfg, torch.float32, device=f"cuda:{device_index}")
     perturb_trainables(model, seed=1000 + rank)                 # replicas start DIFFERENT ...
     opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=0.01, betas=(0.9, 0.95),
                      flat=model.flat_params())
     net = DataParallel(model)                                   # ... and must leave here identical
     flat = model.flat_params()
-    trace = {"p_init": flat.flat.detach().cpu().clone()}
+    trace = {"p_init": flat.flat.detach().cpu().clone(), "backend": dist.get_backend(), "multi_device": multi,
+             "problems": diag["problems"]}
     scaler = misc.NativeScalerWithGradNormCount()
     step_no = {"i": 0}
+
+    from fvqa import ops
+    word = ops.gemm_workspace(torch.device("cuda", device_index))[:8]      # this rank's persistent-GEMM workspace: its error word
 
     def sync():
         if step_no["i"] == INF_STEP and rank == INF_RANK:       # an overflow on ONE rank
             flat.flat_grad[7] = float("inf")
+        word.view(torch.int64)[0] = 1 if (step_no["i"] == ERR_STEP and rank == ERR_RANK) else 0
         return net.sync_grads()
 
     opt.grad_sync = sync
@@ -114,6 +131,7 @@ def main():
         trace[f"scale{i}"] = float(scaler._scale.item())
         trace[f"found{i}"] = float(scaler._found.item())
         trace[f"step{i}"] = float(opt.step_dev.item())
+    word.view(torch.int64)[0] = 0
     model._engine.check_gemm_error()                            # (two persistent grids share this GPU: no exchange timed out)
     torch.save(trace, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

@@ -117,3 +117,50 @@ def test_dataparallel_broadcasts_rank0_state_and_averages_grads(tmp_path):
     assert torch.equal(r0["grad"], want) and torch.equal(r1["grad"], want)
     for k, v in (("m", 0.0), ("v", 0.0), ("step", 3.0)):
         assert torch.all(r0[k] == v) and torch.all(r1[k] == v)
+
+
+class _FlatLane(_Flat):
+    """as fvqa.step.FlatParams: the gradients and, behind them, the error lane in ONE buffer"""
+    def __init__(self, rank):
+        super().__init__(rank)
+        self.grad_store = torch.cat([self.flat_grad, torch.zeros(4)])
+        self.flat_grad = self.grad_store[:1000]
+        self.err_lane = self.grad_store[1000:1001]
+
+
+class _ModuleLane(_Module):
+    def __init__(self, rank):
+        torch.nn.Module.__init__(self)
+        self._f = _FlatLane(rank)
+
+
+def _lane_worker(rank, world, port, out_dir):
+    from fvqa.parallel import DataParallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _ModuleLane(rank)
+    net = DataParallel(m)
+    out = {}
+    for step, faulty in enumerate((None, 1, None)):                  # step 1: rank 1's persistent GEMM timed out
+        word = torch.tensor([1 if faulty == rank else 0], dtype=torch.int64).view(torch.uint8)
+        net.error_word = lambda w=word: w
+        g_local = m.flat_params().flat_grad.clone()
+        net.sync_grads()
+        out[step] = dict(lane=float(m.flat_params().err_lane[0]), grad=m.flat_params().flat_grad.clone(), g_local=g_local)
+    torch.save(out, os.path.join(out_dir, f"lane{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gemm_error_word_of_one_rank_reaches_every_rank_with_the_gradients(tmp_path):
+    """A timed-out split-K exchange on ONE rank (its workspace's error word) must make ALL replicas skip the step: the flag
+    rides as one more element of the gradient all-reduce (FlatParams.err_lane; fvqa_grad_unscale_norm turns a non-zero lane
+    into found_inf = 2 on every rank). Checked here: the lane after sync_grads is 0 / non-zero / 0 again on BOTH ranks for a
+    clean / faulty-on-rank-1 / clean step, and the gradients next to it are still the plain sum."""
+    world, port = 2, _free_port()
+    mp.spawn(_lane_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "lane0.pt"), torch.load(tmp_path / "lane1.pt")
+    for step, want in ((0, 0.0), (1, 1.0), (2, 0.0)):
+        assert r0[step]["lane"] == want and r1[step]["lane"] == want
+        assert torch.equal(r0[step]["grad"], r1[step]["grad"])
+        assert torch.allclose(r0[step]["grad"], r0[step]["g_local"] + r1[step]["g_local"])

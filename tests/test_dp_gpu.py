@@ -47,6 +47,8 @@ def test_two_ranks_stay_bitwise_equal_and_match_single_process_average(tmp_path)
     # replicas: identical start (rank 0's values, although rank 1 was initialised differently) and identical after
     # every step
     assert torch.equal(t0["p_init"], t1["p_init"])
+    # one GPU here: the gloo rehearsal on a shared device; two or more: one rank per device over RCCL, picked automatically
+    assert t0["backend"] == ("nccl" if torch.cuda.device_count() >= world else "gloo") and t0["problems"] == []
     for i in range(W.N_STEPS):
         assert torch.equal(t0[f"p{i}"], t1[f"p{i}"]), f"replicas diverged at step {i}"
         assert t0[f"scale{i}"] == t1[f"scale{i}"] and t0[f"found{i}"] == t1[f"found{i}"]
@@ -55,8 +57,14 @@ def test_two_ranks_stay_bitwise_equal_and_match_single_process_average(tmp_path)
     assert t0[f"found{i}"] == 1.0 and t1[f"found{i}"] == 1.0
     assert torch.equal(t0[f"p{i}"], t0[f"p{i - 1}"])
     assert t0[f"scale{i}"] == 0.5 * t0[f"scale{i - 1}"]
-    assert t0[f"step{i}"] == t0[f"step{i - 1}"] and t0[f"step{W.N_STEPS - 1}"] == W.N_STEPS - 1
-    assert not torch.equal(t0[f"p{i + 1}"], t0[f"p{i}"])            # training resumes afterwards
+    assert t0[f"step{i}"] == t0[f"step{i - 1}"] and t0[f"step{W.N_STEPS - 1}"] == W.N_STEPS - 2
+    # the step on which ONE rank's persistent-GEMM error word was raised: the flag rides in the gradient all-reduce
+    # (FlatParams.err_lane), so BOTH ranks report found_inf = 2, skip the update and — it is not an overflow — keep the scale
+    e = W.ERR_STEP
+    assert t0[f"found{e}"] == 2.0 and t1[f"found{e}"] == 2.0
+    assert torch.equal(t0[f"p{e}"], t0[f"p{e - 1}"]) and t0[f"scale{e}"] == t0[f"scale{e - 1}"]
+    assert t0[f"step{e}"] == t0[f"step{e - 1}"]
+    assert not torch.equal(t0[f"p{e + 1}"], t0[f"p{e}"])            # training resumes afterwards
 
     # ONE process doing both shards and the mean itself (what DDP's all-reduce computes)
     cfg = synth.preset("tiny", vaq=True, qav=True)
@@ -67,7 +75,10 @@ def test_two_ranks_stay_bitwise_equal_and_match_single_process_average(tmp_path)
     opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=0.01, betas=(0.9, 0.95), flat=flat)
     scaler = misc.NativeScalerWithGradNormCount()
     scaler._lazy(flat.flat.device)
+    from fvqa import ops
+    word = ops.gemm_workspace(flat.flat.device)[:8]
     for i in range(W.N_STEPS):
+        word.view(torch.int64)[0] = 1 if i == W.ERR_STEP else 0          # (here: the one process's own error word)
         opt.zero_grad()
         a, b, c = model(synth.make_batch(cfg, seed=W.batch_seed(1, world, i)))
         ((a + b + c) * scaler._scale).sum().backward()
@@ -80,6 +91,7 @@ def test_two_ranks_stay_bitwise_equal_and_match_single_process_average(tmp_path)
         scaler(a + b + c, opt, parameters=None, update_grad=True)
         torch.cuda.synchronize()
         assert torch.equal(flat.flat.cpu(), t0[f"p{i}"]), f"2-rank result != single-process average at step {i}"
+    word.view(torch.int64)[0] = 0
 
 
 def test_one_rank_rccl_group_runs_beside_the_hip_library(tmp_path):

@@ -290,3 +290,44 @@ def test_persistent_gemm_plans_of_the_c2_step():
         p, _ = _sk_plan(1024, N, K, 1)
         assert (p["n_teams"], p["full"], p["rem"], p["s"]) == w and p["ts"] == 4, (N, K, p)
         assert p["pstride"] == (8 if w[3] == 4 else 1)
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """The library carries the hash of the kernel sources it was built from (csrc/version.hip, -DFVQA_SOURCE_HASH); a binary
+    older than the sources next to it — same ABI number, different kernels — must not load."""
+    from fvqa import _lib, build
+    lib = _lib.load()                                     # the in-tree build matches its sources
+    assert lib.fvqa_source_hash().decode() == build.source_hash()
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 64)      # = a kernel source touched after the build
+    with pytest.raises(_lib.FvqaLibraryError, match="stale binary"):
+        _lib.load()
+    monkeypatch.undo()
+    assert _lib.load() is not None
+
+
+def test_rank_startup_checks_name_what_is_wrong():
+    """fvqa/rankcheck.py: the reports every rank gathers before the first data-parallel step (reference train.py:104-117,
+    util/misc.py:220-250): a sound 8-rank node passes; a wrong world size, two ranks on one device, a compute-partitioned
+    device (fewer than 256 CUs), too few devices and unpinned host threads are each named."""
+    from fvqa import rankcheck
+
+    def rep(rank, dev, cus=256, host="n0", ndev=8, omp="8"):
+        return {"rank": rank, "local_rank": rank, "host": host, "device_index": dev, "device_count": ndev,
+                "device_id": f"uuid:gpu-{host}-{dev}", "cu_count": cus, "gcn_arch": "gfx950:sramecc+:xnack-",
+                "omp_num_threads": omp, "cpu_count": 128}
+
+    good = [rep(r, r) for r in range(8)]
+    assert rankcheck.verify(good, 8, 8) == []
+    assert any("were asked for" in p for p in rankcheck.verify(good[:4], 8, 4))
+    shared = [rep(0, 0), rep(1, 0)]
+    assert any("both use device" in p for p in rankcheck.verify(shared, 2, 2))
+    assert rankcheck.verify(shared, 2, 2, rehearsal=True) == []                   # a one-GPU rehearsal may share the device
+    part = [rep(0, 0, cus=32), rep(1, 1)]
+    assert any("32 CUs" in p and "partition" in p for p in rankcheck.verify(part, 2, 2))
+    few = [rep(0, 0, ndev=1), rep(1, 1, ndev=1)]
+    assert any("visible devices" in p for p in rankcheck.verify(few, 2, 2))
+    assert any("OMP_NUM_THREADS" in p for p in rankcheck.verify([rep(0, 0, omp=None), rep(1, 1)], 2, 2))
+    wrong_arch = [dict(rep(0, 0), gcn_arch="gfx942")]
+    assert any("gfx950" in p for p in rankcheck.verify(wrong_arch, 1, 1))
+    assert rankcheck.verify([rep(0, 0, omp=None)], 1, 1) == []                    # a single rank need not pin its threads

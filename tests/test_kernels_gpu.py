@@ -750,7 +750,8 @@ def test_grad_norm_and_adamw_match_torch():
     sc3 = torch.tensor([scale], device=DEV)
     ops.grad_unscale_norm(grad3, seg, sc3, seg_sq, found, norm, ws, grad_div=4.0)
     assert found.item() == 0.0 and torch.equal(grad3, grad)
-    # a set GEMM error word: found_inf = 2, the step is a no-op, the scale backs off
+    # a set GEMM error word: found_inf = 2, the step is a no-op and — a timed-out exchange is not an overflow — the loss scale
+    # and its growth tracker stay as they are
     err = torch.zeros(8, dtype=torch.uint8, device=DEV)
     grad4 = dev(g0 * scale)
     ops.grad_unscale_norm(grad4, seg, sc3, seg_sq, found, norm, ws, gemm_err=err)
@@ -761,8 +762,19 @@ def test_grad_norm_and_adamw_match_torch():
     assert found.item() == 2.0
     before = flat.clone()
     ops.adamw_step(flat, grad4, m, v, 0.05, 0.9, 0.95, 1e-8, 0.14, step, found)
+    tr_before = tracker.item()
     ops.scaler_update(step, sc3, tracker, found, 2.0, 0.5, 2)
-    assert torch.equal(flat, before) and step.item() == 3.0 and sc3.item() == scale * 0.5
+    assert torch.equal(flat, before) and step.item() == 3.0 and sc3.item() == scale and tracker.item() == tr_before
+    # the same through the error LANE (another rank's error word, summed in with the gradients by the all-reduce)
+    err.zero_()
+    lane = torch.zeros(1, device=DEV)
+    grad5 = dev(g0 * scale)
+    ops.grad_unscale_norm(grad5, seg, sc3, seg_sq, found, norm, ws, gemm_err=err, err_lane=lane)
+    assert found.item() == 0.0
+    lane.fill_(1.0)
+    grad5 = dev(g0 * scale)
+    ops.grad_unscale_norm(grad5, seg, sc3, seg_sq, found, norm, ws, gemm_err=err, err_lane=lane)
+    assert found.item() == 2.0
 
 
 def test_gemm_error_word_is_read_back_and_reported():
@@ -811,7 +823,7 @@ def test_set_error_word_skips_the_optimizer_step_and_raises():
     try:
         step()
         assert scaler._found.item() == 2.0
-        assert torch.equal(flat.flat, p1) and scaler._scale.item() == 0.5 * s1
+        assert torch.equal(flat.flat, p1) and scaler._scale.item() == s1        # skipped; not an overflow: no back-off
         with pytest.raises(RuntimeError, match="split-K exchange"):
             model._engine.check_gemm_error()
     finally:

@@ -34,7 +34,15 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int DH = 128;
 constexpr int BQ = 128;                 // queries / keys per workgroup = rows per staged tile
-constexpr int LDR = DH + 8;             // row-major tile leading dim (bf16 elements): 272 B
+// Row pitch of the LDS tiles (bf16 elements). 288 bytes = 72 dwords: consecutive rows start 8 banks apart, so the 8 rows x 32
+// bytes that one 32-lane half of a ds_read_b64_tr_b16 takes (rows rb+4g+q, g in {0,1}, q < 4: 8 dwords each) cover 64 distinct
+// banks, and the ds_read_b128 row fragments stay conflict-free as well. The 272-byte pitch of rounds 1-3 (68 dwords: rows 4
+// banks apart) made those transposed reads 2-way: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.52 in the fused backward, 0.38
+// in the forward (profiles/r03_pmc_mfma_lds.json). -DFVQA_ATTN_LDR=136 rebuilds the old pitch for A/B runs.
+#ifndef FVQA_ATTN_LDR
+#define FVQA_ATTN_LDR 144
+#endif
+constexpr int LDR = FVQA_ATTN_LDR;      // row-major tile leading dim (bf16 elements)
 constexpr int HP = DH / 2;              // rotation pairs per head
 constexpr float NEG_BIG = -1e30f;
 

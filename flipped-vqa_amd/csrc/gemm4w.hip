@@ -120,7 +120,7 @@ extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype,
 // has validated pointers, alignment and leading dimensions. *rode <- 1 when the rider ran inside the launch.
 int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
                      int ldc, int out_dtype, int epilogue, hipStream_t st, const fvqa_sk_rider* rider, int* rode, void* C2,
-                     const fvqa_sk_rope* rope, int n_cu) {
+                     const fvqa_sk_rope* rope, int n_cu, unsigned long long* clock_stamps, unsigned long long epoch) {
   if (rode) *rode = 0;
   if ((size_t)M * lda * 2 >= 0x7fffffffull || (size_t)N * ldb * 2 >= 0x7fffffffull) return FVQA_ESHAPE;   // 32-bit DMA offsets
   G4Args a;
@@ -133,6 +133,11 @@ int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void*
   a.rope_cos = rope ? rope->cos_t : nullptr; a.rope_sin = rope ? rope->sin_t : nullptr;
   a.rope_S = rope ? rope->seq_len : 1; a.rope_cols = rope ? rope->cols : 0; a.rope_hp = rope ? rope->head_dim / 2 : 1;
   a.rope_hmask = (rope && (rope->head_dim & (rope->head_dim - 1)) == 0) ? rope->head_dim - 1 : 0;
+#ifdef FVQA_SK_CLOCK
+  a.clock_stamps = clock_stamps; a.epoch = epoch;
+#else
+  (void)clock_stamps; (void)epoch;
+#endif
   static const bool ride = !(getenv("FVQA_RIDER") && getenv("FVQA_RIDER")[0] == '0');
   const bool rider_ok = ride && rider && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 && rider->N > 0 &&
                         rider->A && rider->B && rider->C;

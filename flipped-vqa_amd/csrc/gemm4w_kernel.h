@@ -24,6 +24,10 @@ struct G4Args {
 #ifdef FVQA_G4_STAMPS
   unsigned long long* stamps;      // tuning builds only: 8 x 100 MHz timestamps per workgroup, memory nothing else reads
 #endif
+#ifdef FVQA_SK_CLOCK
+  unsigned long long* clock_stamps;   // diagnostic build (tools/sk_clock.py): this launch's slice of the stamp ring, or NULL
+  unsigned long long epoch;
+#endif
 };
 
 #ifdef FVQA_G4_STAMPS
@@ -228,7 +232,25 @@ __global__ __launch_bounds__(256) void gemm4w_k(const G4Args a) {
     for (int j = 0; j < NBT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#ifdef FVQA_SK_CLOCK
+    // in-loop shader clock (MI355X_MICROARCH.md "DVFS give-back" item 6): s_memtime / s_memrealtime around the loop of the
+    // first tile, same record as gemm_sk.hip's; the shipping build compiles none of it
+    unsigned long long ct0, cr0, ct1, cr1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct0), "=s"(cr0) :: "memory");
+#endif
     ring4_loop<NBT>(acc, lds0, a.A, a.B, a.M, a.N, a.lda, a.ldb, m0, n0, 0, a.K / 64, w, lane, 0);
+#ifdef FVQA_SK_CLOCK
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ct1), "=s"(cr1) :: "memory");
+    if (tid == 0 && r == 0 && a.clock_stamps) {
+      unsigned long long* st_ = a.clock_stamps + (size_t)slot * 16;
+      st_[0] = ct0; st_[1] = cr0; st_[2] = ct1; st_[3] = cr1;
+      st_[4] = ((unsigned long long)(unsigned)a.N << 32) | (unsigned)a.K;
+      st_[5] = a.epoch;
+      st_[6] = (unsigned long long)EPI | (1ull << 8) | ((unsigned long long)(a.K / 64) << 16) | ((unsigned long long)NBT << 32) |
+               ((unsigned long long)sizeof(TO) << 40) | ((unsigned long long)a.grid << 48);
+      st_[7] = (unsigned long long)a.M;
+    }
+#endif
     // Everything below is addressed from opaque copies of (lane, wave, tile origin): the epilogue's per-lane address
     // arithmetic must not be hoisted above the loop statement (it owns v64-v231 there)
     int lane_e = lane, w_e = w, m0_e = m0, n0_e = n0;

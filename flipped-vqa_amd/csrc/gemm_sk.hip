@@ -604,7 +604,7 @@ extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype,
                                   int n_cu);
 int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
                      int ldc, int out_dtype, int epilogue, hipStream_t st, const fvqa_sk_rider* rider, int* rode, void* C2,
-                     const fvqa_sk_rope* rope, int n_cu);
+                     const fvqa_sk_rope* rope, int n_cu, unsigned long long* clock_stamps, unsigned long long epoch);
 
 // C[M,N] = A[M,K] x B[N,K]^T with the epilogue applied once per finished tile. `ws`: fvqa_gemm_sk_workspace()
 // bytes whose first 4096 were zeroed once by the caller after allocation (epoch flags; never reset afterwards).
@@ -637,7 +637,16 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     const fvqa_sk_plan p0 = fvqa_sk_make_plan(M, N, K, 64, cus);
     if (!(p0.full == 0 && p0.s > 1)) {
       const int nbt = fvqa_gemm4w_choose(M, N, K, dtype, out_dtype, epilogue, rider, cus);
-      if (nbt) return fvqa_gemm4w_impl(nbt, A, B, C, R, M, N, K, lda, ldb, ldc, out_dtype, epilogue, st, rider, rode, C2, rope, cus);
+      if (nbt) {
+        unsigned long long* cst = nullptr;
+        unsigned long long ep = 0;
+#ifdef FVQA_SK_CLOCK
+        ep = g_epoch.fetch_add(1) + 1;
+        cst = (u64*)((char*)ws + SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float)) + (size_t)(ep % CLOCK_RING) * 256 * 16;
+#endif
+        return fvqa_gemm4w_impl(nbt, A, B, C, R, M, N, K, lda, ldb, ldc, out_dtype, epilogue, st, rider, rode, C2, rope, cus, cst,
+                                ep);
+      }
     }
   }
   a.sync = (u64*)ws;

@@ -13,6 +13,18 @@ dataset_mapping = {"nextqa": NextQA}
 num_options_mapping = {"nextqa": 5}
 
 
+def _worker_init(worker_id):
+    """Loader workers yield to the training process: it is the one thread per rank whose stalls idle a GPU (a descheduled
+    launch thread costs device time; a late batch only matters after `depth` batches of slack). Lower priority (best effort:
+    os.nice needs no privilege to go down) and one intra-op thread each."""
+    import os
+    try:
+        os.nice(int(os.environ.get("FVQA_LOADER_NICE", "10")))
+    except OSError:
+        pass
+    torch.set_num_threads(1)
+
+
 def load_data(args, tokenizer, split="train"):
     if args.dataset not in dataset_mapping:
         raise NotImplementedError(f"dataset {args.dataset!r}: only {sorted(dataset_mapping)} are built")
@@ -22,7 +34,9 @@ def load_data(args, tokenizer, split="train"):
                                                   rank=misc.get_rank(), shuffle=split == "train")
     return torch.utils.data.DataLoader(dataset, sampler=sampler, batch_size=args.batch_size,
                                        num_workers=args.num_workers, collate_fn=batch_collate,
-                                       pin_memory=args.pin_mem, drop_last=False)
+                                       pin_memory=args.pin_mem, drop_last=False,
+                                       worker_init_fn=_worker_init if args.num_workers > 0 else None,
+                                       persistent_workers=args.num_workers > 0 and split == "train")
 
 
 def batch_collate(batch):

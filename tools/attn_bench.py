@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Attention forward / backward kernel times (bf16 build, RoPE inside) at the benchmark shapes: C2 (8 x 128), C3 (24 x 128),
-C4 (3 x 650); HIP events, median of 20. FVQA_ATTN_FWD32=0/1 forces the 16- / 32-query forward."""
+"""Attention forward / backward kernel times (bf16 build) at the benchmark shapes: C2 (8 x 128), C3 (24 x 128), C4 (3 x 650);
+HIP events, median of 20. Default: the step's form — q, k arrive rotated by the QKV projection's epilogue, the forward runs
+without tables and the backward un-rotates dq / dk at its store (attn_bwd(..., prerotated=True)); AB_RAW=1: the round-2 form
+(raw q, k rotated inside every kernel). FVQA_ATTN_FWD32=0/1 forces the 16- / 32-query forward."""
 import os
 import sys
 
@@ -43,6 +45,11 @@ for name, N, S in [("C2", 8, 128), ("C3", 24, 128), ("C4", 3, 650), ("S256", 12,
                 ts.append(e0.elapsed_time(e1) * 1e3)
         return sorted(ts)[len(ts) // 2]
 
-    tf = timed(lambda: ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope))
-    tb = timed(lambda: ops.attn_bwd(d_o, qkv, o, la, lt, g1, g2, vs, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, rope=rope))
+    if os.environ.get("AB_RAW") == "1":
+        tf = timed(lambda: ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope))
+        tb = timed(lambda: ops.attn_bwd(d_o, qkv, o, la, lt, g1, g2, vs, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, rope=rope))
+    else:
+        tf = timed(lambda: ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F))
+        tb = timed(lambda: ops.attn_bwd(d_o, qkv, o, la, lt, g1, g2, vs, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, rope=rope,
+                                        prerotated=True))
     print(f"{name:5s} n_seq={N:3d} S={S:4d}: forward {tf:7.1f} us   backward {tb:7.1f} us", flush=True)

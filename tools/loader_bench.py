@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--model", default="7B")
     ap.add_argument("--n_layers", type=int, default=0)
+    ap.add_argument("--sweep", default="", help="comma list of worker counts: repeat the epoch measurement (c) with each")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     root = tempfile.mkdtemp()
@@ -156,7 +157,17 @@ def main():
     t_short, t_long = epoch(a.steps), epoch(3 * a.steps)     # the difference leaves out the start of the loader's workers
     loop = 2 * a.steps * a.batch_size / (t_long - t_short)
     print(f"engine.train_one_epoch fed by the producer: {loop:7.1f} samples/s ({loop / pre * 100:.1f} % of the bare step; "
-          f"{a.steps} / {3 * a.steps} iterations took {t_short:.2f} / {t_long:.2f} s)")
+          f"{a.steps} / {3 * a.steps} iterations took {t_short:.2f} / {t_long:.2f} s; {a.workers} workers, "
+          f"{torch.get_num_threads()} torch threads, {len(os.sched_getaffinity(0))} CPUs)", flush=True)
+    for w in [int(x) for x in a.sweep.split(",") if x.strip()]:
+        args.num_workers = w
+        loader = dataloader.load_data(args, tok, split="train")
+        epoch(6)
+        pre_w = timed(staged[i % 4] for i in range(5 + a.steps))        # the bare step again, right beside it
+        t_short, t_long = epoch(a.steps), epoch(3 * a.steps)
+        loop = 2 * a.steps * a.batch_size / (t_long - t_short)
+        print(f"  sweep: {w} workers: train_one_epoch {loop:7.1f} samples/s = {loop / pre_w * 100:.1f} % of the bare step "
+              f"({pre_w:.1f} samples/s measured beside it)", flush=True)
 
 
 if __name__ == "__main__":

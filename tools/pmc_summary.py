@@ -10,7 +10,9 @@ where a pass holds the inputs:
                    launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs; a busy cycle is counted per SIMD)
   lds_conflict_frac SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
   wait_frac        SQ_WAIT_ANY / SQ_WAVE_CYCLES; issue_stall_frac = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
-  clock_ghz        GRBM_GUI_ACTIVE / 8 / duration (reads high on launches shorter than ~0.3 ms)
+The shader clock is NOT derived here: GRBM_GUI_ACTIVE / 8 / duration reads high on launches shorter than ~0.3 ms (it gave
+4.8 GHz for the RMSNorm kernels of a 2.4 GHz part); the in-loop clock comes from s_memtime / s_memrealtime stamps of the
+diagnostic build, tools/sk_clock.py -> profiles/r04_clock.log.
 """
 import csv
 import glob
@@ -19,7 +21,7 @@ import os
 import re
 import sys
 
-KEEP = ("gemm_sk_256", "attn_fwd_mfma_k", "attn_bwd_fused_k", "rmsnorm_fwd_k", "rmsnorm_bwd_k", "gemm_nt_skinny")
+KEEP = ("gemm_sk_256", "fvqa_g4::gemm4w_k", "attn_fwd_mfma_k", "attn_bwd_fused_k", "rmsnorm_fwd_k", "rmsnorm_bwd_k", "gemm_nt_skinny")
 N_CU = 256
 
 
@@ -59,7 +61,6 @@ def main():
             e["hbm_bytes_per_launch"] = e["fetch_bytes_per_launch_corrected"] + e["write_bytes_per_launch"]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
             e["mfma_busy_frac"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["GRBM_GUI_ACTIVE"] / 8 * 4 * N_CU)
-            e["clock_ghz"] = avg["GRBM_GUI_ACTIVE"] / 8 / (dur["GRBM_GUI_ACTIVE"] * 1e3)
             e["avg_duration_us_under_pmc"] = dur["GRBM_GUI_ACTIVE"]
         if "SQ_LDS_BANK_CONFLICT" in avg and "SQ_LDS_IDX_ACTIVE" in avg and avg["SQ_LDS_IDX_ACTIVE"] > 0:
             e["lds_conflict_frac"] = avg["SQ_LDS_BANK_CONFLICT"] / avg["SQ_LDS_IDX_ACTIVE"]

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Profiles of the default bench (C2) on the MI355X box; everything lands under $1 (default gpurun_out/r3prof).
+# Profiles of the default bench (C2) on the MI355X box; everything lands under $1 (default gpurun_out/r4prof).
 #   1. rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 5` (per-kernel durations + the bench's own line)
 #   2. four SEPARATE --pmc passes of `bench.py --steps 2 --warmup 1` (counters never share a run with the stats trace)
 #   3. tools/pmc_summary.py over the passes, tagged with the hash of the kernel sources they ran on
-out=${1:-gpurun_out/r3prof}
+out=${1:-gpurun_out/r4prof}
 mkdir -p $out
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 20 --warmup 5 --no_cpu_baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err || exit 1

@@ -48,20 +48,23 @@ def summarise(st, min_epoch, label=""):
         used = blk[:, 1] > 0
         if not bool(used.any()):
             continue
-        b = blk[used]
-        ep = int(b[0, 5])
+        ep = int(blk[used][:, 5].max())                  # a slice is reused every RING launches: this launch's rows only
         if ep < min_epoch:
             continue
+        used = used & (blk[:, 5] == ep)
+        b = blk[used]
         N, K = int(b[0, 4]) >> 32, int(b[0, 4]) & 0xFFFFFFFF
         meta = int(b[0, 6])
-        epi, split, nw, ob, nwg = meta & 0xFF, (meta >> 8) & 0xFF, (meta >> 16) & 0xFFFFFF, (meta >> 40) & 0xFF, (meta >> 48)
+        epi, split, nw, nbt, ob, nwg = (meta & 0xFF, (meta >> 8) & 0xFF, (meta >> 16) & 0xFFFF, (meta >> 32) & 0xFF,
+                                        (meta >> 40) & 0xFF, (meta >> 48))
+        nbt = nbt or 16                                   # gemm_sk_256: 256-column tiles; gemm4w_k: 16 * NBT columns
         M = int(b[0, 7])
         dt = (b[:, 2] - b[:, 0]).double()
         dr = (b[:, 3] - b[:, 1]).double()
         ok = dr > 0
         clk = (dt[ok] / dr[ok] * 0.1)                       # GHz
         us = dr[ok] / 100.0
-        key = (M, N, K, epi, split, ob)
+        key = (M, N, K, epi, split, ob, nbt)
         e = rows.setdefault(key, {"n": 0, "clk": [], "us": [], "nw": nw, "wgs": int(used.sum()), "nwg": nwg})
         e["n"] += 1
         e["clk"].append(float(clk.median()))
@@ -73,13 +76,13 @@ def summarise(st, min_epoch, label=""):
           f"(median of per-launch medians; min / max over workgroups), loop us, TF/s inside the loop (all workgroups)")
     tot_flop = tot_cyc = 0.0
     for key in sorted(rows):
-        M, N, K, epi, split, ob = key
+        M, N, K, epi, split, ob, nbt = key
         e = rows[key]
         import statistics as S
         clk, us = S.median(e["clk"]), S.median(e["us"])
-        # FLOPs inside the stamped loops: every stamped workgroup runs a 256 x 256 x (nw * 64) product
-        fl = e["wgs"] * 2.0 * 256 * 256 * e["nw"] * 64
-        print(f"{M:5d} x {N:6d} x {K:6d} {epi_name.get(epi, epi):14s} split {split} out{ob}B  n={e['n']:3d} wgs={e['wgs']:3d} "
+        # FLOPs inside the stamped loops: every stamped workgroup runs a 256 x (16 nbt) x (nw * 64) product
+        fl = e["wgs"] * 2.0 * 256 * 16 * nbt * e["nw"] * 64
+        print(f"{M:5d} x {N:6d} x {K:6d} {epi_name.get(epi, epi):14s} split {split} tile 256x{16 * nbt:3d} out{ob}B  n={e['n']:3d} wgs={e['wgs']:3d} "
               f"nw={e['nw']:4d}  clock {clk:5.3f} GHz ({min(e['clk_min']):.3f} / {max(e['clk_max']):.3f})  loop {us:7.1f} us  "
               f"{fl / us / 1e6:7.0f} TF/s  -> MFMA pipe busy in-loop {fl / us / 1e6 / (256 * 4096 * clk * 1e-3) * (256 / e['wgs']):.3f} of the busy CUs' cycles")
         tot_flop += fl * e["n"]
@@ -138,7 +141,7 @@ def mode_step(seconds):
     ws = ops.gemm_workspace(dev, need)
     st = read_ring(ws, need)
     last = int(st[:, :, 5].max())
-    summarise(st, last - 257, "C2 step, last 258 launches")
+    summarise(st, last - 257, "C2 step, last 258 launches (gemm_sk_256: split 2/4; gemm4w_k: split 1, first tile of a workgroup)")
 
 
 def mode_b2b(seconds):

@@ -10,8 +10,10 @@
 // what the full-sequence kernel + two torch index ops did per token and layer before (13.5 us + glue for 256 (n, h)
 // pairs against one streaming pass over 64 KiB of cached K/V per pair here).
 // HBM-bound (K/V read once: 2 * (p+1+A) * 256 B per pair); no matrix cores: a 1-row product has nothing to feed them.
-// cache_rot: 0 = the cache holds RAW k (bf16 build: the attention kernels rotate on the fly), 1 = ROTATED k (fp32
-// vector build). One workgroup (4 waves) per (head, sequence): a quad of lanes per key in the score pass (64-byte
+// cache_rot: 1 = the cache holds ROTATED k — the fp32 vector build, and the bf16 build when the QKV projection rotates q, k in
+// its epilogue (fvqa_rope_in_gemm, the default); 0 = RAW k (bf16 build with FVQA_ROPE_IN_GEMM=0: the attention kernels
+// rotate on the fly). The caller's rule: cache_rotated = !fvqa_attn_rope_fused(dtype) || fvqa_rope_in_gemm(dtype). The new
+// token's rotated q and k are rounded to the storage type before use, as the prefill's are. One workgroup (4 waves) per (head, sequence): a quad of lanes per key in the score pass (64-byte
 // contiguous reads per quad), one lane per pair of head dims in the value pass (256-byte rows per wave instruction).
 #include "common.h"
 
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(256) void attn_decode_k(const T* __restrict__ qkv_r
     const int c = part_id + 4 * u;
     Chunk<T>::load(rowq + c * CH, q[u]);
     rope_chunk<CH>(q[u], cs, sn, p, c * CH);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) q[u][e] = round_to<T>(q[u][e]);     // as the prefill holds it: rotated, in the storage type
   }
   auto dot_row = [&](const T* krow, int rot_pos, bool rot) {      // rot == false: the row is used as stored
     float acc = 0.f;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_decode_k(const T* __restrict__ qkv_r
       Chunk<T>::load(krow + c * CH, k);
       rope_chunk<CH>(k, cs, sn, rot_pos, c * CH, rot);
 #pragma unroll
-      for (int e = 0; e < CH; ++e) acc += q[u][e] * k[e];
+      for (int e = 0; e < CH; ++e) acc += q[u][e] * (rot ? round_to<T>(k[e]) : k[e]);   // a key rotated here is rounded as a stored one
     }
     return quad_sum(acc);
   };

@@ -335,9 +335,16 @@ __device__ __forceinline__ void store_swiglu(f32x4 (&acc)[8][4], char* smem, con
 // wave (4 accumulator quads = 16 values per lane) packs into three 16-byte words: each quad's first three values keep
 // their top three bytes, the freed low bytes carry the fourth value. Deterministic, so results stay bitwise repeatable;
 // the workgroup's own partial enters the sum unrounded. fp32-output launches exchange plain fp32.
+// A non-finite partial must stay non-finite (the loss scaler's overflow check sees the reduced tile): the rounding increment
+// is skipped when the exponent is all ones — added to a NaN whose mantissa bits 7..22 are all set it would carry into the
+// exponent and sign and leave -0 or a tiny finite value. (Inf stays Inf, a NaN stays a NaN or, if only its low byte was set,
+// becomes Inf.)
+__device__ __forceinline__ unsigned round24(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x7F800000u) == 0x7F800000u ? u : u + 0x80u;
+}
 __device__ __forceinline__ void pack24(const f32x4& q, unsigned (&d)[3]) {
-  const unsigned u0 = __float_as_uint(q[0]) + 0x80u, u1 = __float_as_uint(q[1]) + 0x80u;
-  const unsigned u2 = __float_as_uint(q[2]) + 0x80u, u3 = __float_as_uint(q[3]) + 0x80u;
+  const unsigned u0 = round24(q[0]), u1 = round24(q[1]), u2 = round24(q[2]), u3 = round24(q[3]);
   d[0] = __builtin_amdgcn_perm(u0, u3, 0x07060503u);     // bytes: u3.b3 | u0.b1 u0.b2 u0.b3
   d[1] = __builtin_amdgcn_perm(u1, u3, 0x07060502u);     //        u3.b2 | u1.b1..b3
   d[2] = __builtin_amdgcn_perm(u2, u3, 0x07060501u);     //        u3.b1 | u2.b1..b3

@@ -60,8 +60,9 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
                 ops.rmsnorm_fwd(x, pk.an[i], xn, None, eng.eps, rows=B)
                 ops.gemm_nt(xn, pk.wqkv[i], qkv_row)
                 g1, g2 = m.gate_views(i)
-                # the new row against the cached keys / values (+ adapter prefix); its k, v join the cache. The bf16
-                # build caches RAW keys (rotated on the fly), the fp32 vector build rotated ones.
+                # the new row against the cached keys / values (+ adapter prefix); its k, v join the cache. The cache holds
+                # ROTATED keys (fp32 build; bf16 build with RoPE in the QKV epilogue, the default) unless the bf16 build runs
+                # with FVQA_ROPE_IN_GEMM=0 (raw keys, rotated on the fly): cache_rotated = !attn_rope_fused || rope_in_gemm
                 ops.attn_decode(qkv_row, ar.qkv[i], o_row, g1, g2, vstart, pos, (eng.cos, eng.sin), B, S, H, Dh, A, F,
                                 cache_rotated=not fused)
                 ops.gemm_nt(o_row, pk.wo[i], h, residual=x)

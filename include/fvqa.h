@@ -209,9 +209,12 @@ int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const fl
 /* One-query-row attention of the generation path (llama/model.py:428-470 re-runs the whole sequence per new token; this
  * evaluates Attention.forward :87-128 at the new row only). qkv_row (n_seq, 3*dim): RAW q | k | v projections of each
  * sequence's new token, whose position is pos[n] (int64, device). qkv_cache: the layer's (n_seq*S + A, 3*dim) buffer of
- * fvqa_attn_fwd, holding the keys / values of positions < pos[n] (RAW k when cache_rotated == 0 — the bf16 build, rotated
- * on the fly —, ROTATED k when 1 — the fp32 build) and the adapter rows; the kernel rotates the new q and k with the
- * tables, writes o_row (n_seq, dim) and stores the new token's k (in the cache's convention) and v into cache row
+ * fvqa_attn_fwd, holding the keys / values of positions < pos[n] and the adapter rows. cache_rotated says what the cache
+ * holds: 1 = ROTATED k (the fp32 build; the bf16 build when the QKV projection rotates in its epilogue, fvqa_rope_in_gemm —
+ * the default), 0 = RAW k (bf16 build with FVQA_ROPE_IN_GEMM=0, rotated on the fly); the rule for a caller is
+ * cache_rotated = !fvqa_attn_rope_fused(dtype) || fvqa_rope_in_gemm(dtype) — passing 0 for a rotated cache would rotate the
+ * cached keys twice. The kernel rotates the new q and k with the tables (rounded to the storage type, as the prefill holds
+ * them), writes o_row (n_seq, dim) and stores the new token's k (in the cache's convention) and v into cache row
  * n*S + pos[n]. seq_len <= 4096. */
 int fvqa_attn_decode(const void* qkv_row, void* qkv_cache, void* o_row, const float* gate1, const float* gate2,
                      const int32_t* vstart, const int64_t* pos, const float* cos_t, const float* sin_t, int n_seq,

@@ -75,6 +75,28 @@ def test_generation_matches_reference(dtype, pname):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rope_in_gemm", ["0", "1"])
+def test_bf16_generation_is_pinned_in_both_rope_modes(rope_in_gemm):
+    """The KV cache of the generation path holds ROTATED keys when the QKV projection rotates in its epilogue (the default,
+    FVQA_ROPE_IN_GEMM=1) and RAW keys otherwise; fvqa_attn_decode is told which (cache_rotated = !attn_rope_fused ||
+    rope_in_gemm). Either way the bf16 build reproduces the reference's tokens on the peaked fixtures. The switch is read once
+    per process, so each mode runs in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch, tests.test_eval as T\n"
+            "from fvqa import ops\n"
+            f"assert ops.rope_in_gemm(torch.bfloat16) == {rope_in_gemm == '1'}\n"
+            "for p in ('tiny_peaked', '7b_l2_peaked'):\n"
+            "    T.test_generation_matches_reference(torch.bfloat16, p)\n"
+            "print('ok')\n")
+    env = dict(os.environ, FVQA_ROPE_IN_GEMM=rope_in_gemm, FVQA_SYNTHETIC_TOKENIZER="1",
+               PYTHONPATH=os.pathsep.join([root, os.path.join(root, "flipped-vqa_amd"), os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
 def test_val_one_epoch_with_the_model_reports_the_references_accuracy(tmp_path):
     """engine.val_one_epoch driving the real model (fp32 build, 7B width) over the reference's validation batch: accuracy and
     per-type meters are those of the reference's own choices (fixture), the answers file is written per batch."""

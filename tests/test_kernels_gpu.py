@@ -777,6 +777,31 @@ def test_grad_norm_and_adamw_match_torch():
     assert found.item() == 2.0
 
 
+def test_split_k_exchange_keeps_non_finite_partials_non_finite():
+    """The overflow-skip contract of the loss scaler relies on Inf / NaN surviving every bf16-output split-K launch: the 24-bit
+    slab format rounds by an integer increment, which must not carry a NaN's all-ones mantissa into exponent and sign. One
+    poisoned activation element per 256-row tile (Inf, -Inf, the canonical NaN, NaNs with every mantissa bit set, either sign),
+    in different K pieces: the output rows that see it must come out non-finite, every other row finite."""
+    M, N, K = 1024, 4096, 4096                                  # 64 tiles for 256 CUs: 4 pieces per tile, reduced in the launch
+    a = rnd(M, K, dtype=torch.bfloat16, seed=5)
+    b = rnd(N, K, dtype=torch.bfloat16, scale=1 / 64, seed=6)
+    bits = {3: 0x7F80, 300: 0xFF80, 600: 0x7FC0, 700: 0x7FFF, 900: 0xFFFF}       # row -> bf16 pattern
+    ai = a.view(torch.int16).clone()
+    for k_piece, (row, pat) in enumerate(bits.items()):
+        ai[row, (k_piece % 4) * 1024 + 17] = pat - 0x10000 if pat >= 0x8000 else pat
+    a = ai.view(torch.bfloat16)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(dev(a), dev(b), out)
+    torch.cuda.synchronize()
+    fin = torch.isfinite(out.float()).all(dim=1).cpu()
+    for row in bits:
+        assert not bool(torch.isfinite(out[row].float()).any()), f"row {row}: a non-finite partial came out finite"
+    ok = torch.ones(M, dtype=torch.bool)
+    ok[list(bits)] = False
+    assert bool(fin[ok].all())
+    assert ops.gemm_error(device=out.device) == 0
+
+
 def test_gemm_error_word_is_read_back_and_reported():
     """The first word of a persistent-GEMM workspace is its error word (include/fvqa.h): zero after ordinary launches;
     a non-zero word makes the engine's check raise."""

@@ -25,6 +25,11 @@ vs = torch.full((N,), 19, dtype=torch.int32, device=dev)
 ang = torch.outer(torch.arange(2 * S, device=dev, dtype=torch.float32),
                   1.0 / (10000.0 ** (torch.arange(0, Dh, 2, device=dev).float() / Dh)))
 rope = (ang.cos().contiguous(), ang.sin().contiguous())
+# the step's form by default: q, k arrive rotated (RoPE in the QKV projection's epilogue), the forward runs without tables and
+# the backward un-rotates dq / dk at its store; AB_RAW=1: the round-2 form (raw q, k rotated inside every kernel)
+RAW = os.environ.get("AB_RAW") == "1"
+FWD_KW = dict(rope=rope) if RAW else {}
+BWD_KW = dict(rope=rope) if RAW else dict(rope=rope, prerotated=True)
 o = torch.empty(N * S, D, dtype=torch.bfloat16, device=dev)
 la = torch.empty(N * H * S, device=dev)
 lt = torch.empty_like(la)
@@ -48,10 +53,10 @@ if os.environ.get("AB_FWD"):
     raw.fvqa_attn_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
     buf = np.zeros(1024 * 16, dtype=np.uint64)
     for _ in range(5):
-        ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope)
+        ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, **FWD_KW)
     torch.cuda.synchronize()
     raw.fvqa_attn_stamps_read(buf.ctypes.data, 1)
-    ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope)
+    ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, **FWD_KW)
     torch.cuda.synchronize()
     raw.fvqa_attn_stamps_read(buf.ctypes.data, 0)
     nqb = (S + 127) // 128
@@ -71,12 +76,12 @@ if os.environ.get("AB_FWD"):
     sys.exit(0)
 raw.fvqa_attn_stamps_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = np.zeros(1024 * 16, dtype=np.uint64)
-ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, rope=rope)
+ops.attn_fwd(qkv, o, la, lt, g1, g2, vs, N, S, H, Dh, A, F, **FWD_KW)
 for _ in range(5):
-    ops.attn_bwd(d_o, qkv, o, la, lt, g1, g2, vs, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, rope=rope)
+    ops.attn_bwd(d_o, qkv, o, la, lt, g1, g2, vs, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, **BWD_KW)
 torch.cuda.synchronize()
 raw.fvqa_attn_stamps_read(buf.ctypes.data, 1)
-ops.attn_bwd(d_o, qkv, o, la, lt, g1, g2, vs, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, rope=rope)
+ops.attn_bwd(d_o, qkv, o, la, lt, g1, g2, vs, dqkv, dg1, dg2, ws, N, S, H, Dh, A, F, **BWD_KW)
 torch.cuda.synchronize()
 raw.fvqa_attn_stamps_read(buf.ctypes.data, 0)
 st = buf.reshape(1024, 16)[: N * H].astype(np.float64)

@@ -262,6 +262,35 @@ int main(int argc, char** argv) {
   }
 
   if (argc > 1 && !strcmp(argv[1], "epi")) return epi_mode(argc > 2 ? atoi(argv[2]) : 300);
+  if (argc > 1 && !strcmp(argv[1], "split")) {
+    // loop of a split-K piece on 256 workgroups: 256 x 256 tiles cut 4 ways along K (the shipped partition of the N = 4096
+    // outputs) against 256 x 128 tiles cut 2 ways (a third of the exchange bytes per workgroup)
+    struct Sp { const char* name; int N, K, kdiv, nbt; };
+    const Sp sp[] = {{"wo   256x256 /4", 16384, 4096, 4, 16}, {"wo   256x128 /2", 8192, 4096, 2, 8},
+                     {"w2   256x256 /4", 16384, 11008, 4, 16}, {"w2   256x128 /2", 8192, 11008, 2, 8},
+                     {"qkvt 256x256 /4", 16384, 12288, 4, 16}, {"qkvt 256x128 /2", 8192, 12288, 2, 8},
+                     {"w13t 256x256 /4", 16384, 22016, 4, 16}, {"w13t 256x128 /2", 8192, 22016, 2, 8}};
+    const int reps = argc > 2 ? atoi(argv[2]) : 1500;
+    unsigned long long* stamps;
+    CK(hipMalloc(&stamps, 256 * 4 * 8));
+    std::vector<unsigned short> hA((size_t)1024 * 22016), hB((size_t)16384 * 22016);
+    fill(hA, 1.f, 3); fill(hB, 1.f / 64.f, 4);
+    bf16_t *dA, *dB, *dC;
+    CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dB, hB.size() * 2)); CK(hipMalloc(&dC, (size_t)1024 * 16384 * 2));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    for (int round = 0; round < 3; ++round)
+      for (const Sp& s : sp) {
+        PArgs a{dA, dB, dC, 1024, s.N, s.K, 22016, 22016, s.N, 0, 0, s.kdiv, stamps};
+        dispatch(s.nbt, a, reps / 4, 256);
+        double clk = 0, lus = 0;
+        const float us = dispatch(s.nbt, a, reps, 256, &clk, &lus);
+        const double fl = 2.0 * 1024 * s.N * (s.K / s.kdiv);
+        printf("%-16s K %5d: %7.1f us/launch %6.0f TF/s | loop %6.1f us, clock %.3f GHz\n", s.name, s.K, us, fl / us / 1e6, lus, clk);
+        fflush(stdout);
+      }
+    return 0;
+  }
   // timing: C2 shapes. name, M, N, K, kdiv (K range per workgroup = K / kdiv: the loop of a split-K piece, no exchange)
   struct Sh { const char* name; int M, N, K, kdiv; };
   const Sh shapes[] = {{"qkv_fwd", 1024, 12288, 4096, 1}, {"w2t_bwd", 1024, 11008, 4096, 1}, {"w13_fwd", 1024, 22016, 4096, 1},

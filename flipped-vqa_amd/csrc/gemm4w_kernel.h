@@ -74,8 +74,11 @@ __device__ __forceinline__ size_t ab16(int c) { return (size_t)(c >> 4) * 32 + (
 // chunks of a row: 16-byte global accesses, consecutive lanes on consecutive chunks. The epilogue's global operands
 // (residual rows, the saved SwiGLU factors, the RoPE table rows) of a pass are requested BEFORE its staging, so that their
 // latency runs under the LDS round trip instead of once per chunk.
-template <int NBT, typename TO, int EPI>
-__device__ __forceinline__ void store_tile4(f32x16 (&acc)[NBT], char* smem, const G4Args& a, int m0, int n0, int w, int lane) {
+// n_own (1, 2 or 4) / rowxor: a split-K piece stores only the register row blocks [0, n_own) it has reduced; register row block
+// i holds tile row block i ^ (rowxor / 16) of the wave's 64 rows (gemm_sk.hip). ARGS: G4Args or the split-K kernel's SkArgs.
+template <int NBT, typename TO, int EPI, typename ARGS>
+__device__ __forceinline__ void store_tile4(f32x16 (&acc)[NBT], char* smem, const ARGS& a, int m0, int n0, int w, int lane,
+                                            int n_own = 4, int rowxor = 0) {
   constexpr int TN = 16 * NBT, RS = TN + 4;
   constexpr bool SWF = EPI == FVQA_EPI_SWIGLU_FWD_ST, SWB = EPI == FVQA_EPI_SWIGLU_BWD_ST;
   constexpr int IPR = SWF ? TN / 16 : TN / 8;               // work items per row
@@ -85,30 +88,35 @@ __device__ __forceinline__ void store_tile4(f32x16 (&acc)[NBT], char* smem, cons
   float* stg = reinterpret_cast<float*>(smem) + w * (32 * RS);
   const int frow = lane & 15, q4 = lane >> 4;
   const int M = a.M, N = a.N, ldc = a.ldc;
+  const bf16_t* const Rp = reinterpret_cast<const bf16_t*>(a.R);
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const int mrow0 = m0 + 64 * w + 32 * p;
+    if (n_own <= 2 * p) continue;                                         // (wave-uniform)
+    // staged row r of the pass = register row block 2p + (r >> 4), i.e. tile row ((32p + (r & 16)) ^ rowxor) + (r & 15)
+    const int mw0 = m0 + 64 * w;
+    auto row_m = [&](int r) { return mw0 + ((32 * p + (r & 16)) ^ rowxor) + (r & 15); };
+    auto live = [&](int r) { return 2 * p + (r >> 4) < n_own; };
     uint4 pq0[PRE ? IPL : 1], pq1[PRE ? IPL : 1];
     int pos0 = 0;
-    if constexpr (EPI == FVQA_EPI_ROPE) pos0 = mrow0 % a.rope_S;          // (wave-uniform)
+    if constexpr (EPI == FVQA_EPI_ROPE) pos0 = (mw0 + 32 * p) % a.rope_S;        // (wave-uniform; rows are in order when rowxor == 0)
     if constexpr (PRE) {
 #pragma unroll
       for (int t = 0; t < IPL; ++t) {
         const int g = t * 64 + lane;
         const int r = g / IPR, it = g - r * IPR;
-        const int m = mrow0 + r, n = n0 + 8 * it;
+        const int m = row_m(r), n = n0 + 8 * it;
         pq0[t] = pq1[t] = uint4{0u, 0u, 0u, 0u};
-        if ((TOTAL % 64 == 0 || g < TOTAL) && m < M && n < N) {
+        if ((TOTAL % 64 == 0 || g < TOTAL) && live(r) && m < M && n < N) {
           if constexpr (SWB) {
-            const bf16_t* rp = a.R + (size_t)m * ldc + ab16(n);          // (s, t) rows: AB16, 2N columns
+            const bf16_t* rp = Rp + (size_t)m * ldc + ab16(n);           // (s, t) rows: AB16, 2N columns
             pq0[t] = *reinterpret_cast<const uint4*>(rp);
             pq1[t] = *reinterpret_cast<const uint4*>(rp + 16);
           } else if constexpr (EPI == FVQA_EPI_RESIDUAL) {
-            pq0[t] = *reinterpret_cast<const uint4*>(a.R + (size_t)m * ldc + n);
+            pq0[t] = *reinterpret_cast<const uint4*>(Rp + (size_t)m * ldc + n);
           } else {                                                         // RoPE: 4 cos + 4 sin of this chunk's pairs
             if (n < a.rope_cols) {
               int pos = pos0 + r;
-              pos = a.rope_S >= 32 ? (pos >= a.rope_S ? pos - a.rope_S : pos) : pos % a.rope_S;
+              pos = (rowxor == 0 && a.rope_S >= 32) ? (pos >= a.rope_S ? pos - a.rope_S : pos) : m % a.rope_S;
               const int hi = a.rope_hmask ? (n & a.rope_hmask) : (n % (2 * a.rope_hp));
               const size_t ti = (size_t)pos * a.rope_hp + (hi >> 1);
               pq0[t] = *reinterpret_cast<const uint4*>(a.rope_cos + ti);
@@ -133,7 +141,8 @@ __device__ __forceinline__ void store_tile4(f32x16 (&acc)[NBT], char* smem, cons
       const int g = t * 64 + lane;
       if (TOTAL % 64 && g >= TOTAL) continue;
       const int r = g / IPR, it = g - r * IPR;
-      const int m = mrow0 + r;
+      const int m = row_m(r);
+      if (!live(r)) continue;
       if constexpr (SWF) {
         // the tile holds the W1 | W3 projections in AB16 order: blocks (2k, 2k+1) = (a, b) of 16 hidden units; this item is
         // half h of pair k. z = silu(a) * b from the values ROUNDED to bf16 (llama/model.py:142); the a / b slots of C get

@@ -65,4 +65,27 @@ __device__ __forceinline__ void ring4_loop(f32x16 (&acc)[NBT], unsigned lds0, co
   Ring4Asm<NBT>::run(acc, pa, pb, rsAB2, str8, wl, (unsigned)(kel0 * 2), (unsigned)nw, voffA, voffB, rdA, rdB);
 }
 
+// The split-K form (256-column tiles, nw > 0): the loop and, inside the same statement, the exchange of the tile's pieces
+// (Ring4AsmSK). xp: lane k holds exchange parameter k (Ring4AsmSK::XP_*); fa: lane q < np - 1 holds the address of partner
+// q's epoch flag. On return register row blocks [0, 4 / np) hold the reduced tile rows of this piece, every wave has passed
+// a barrier after its last ring read, and the ring memory may be reused.
+__device__ __forceinline__ void ring4_loop_sk(f32x16 (&acc)[16], unsigned lds0, const bf16_t* __restrict__ A,
+                                              const bf16_t* __restrict__ B, int M, int N, int lda, int ldb, int m0, int n0,
+                                              size_t kel0, int nw, int w, int lane, int rowxor, unsigned xp,
+                                              unsigned long long fa) {
+  if (nw <= 0) return;                                    // (never taken: a piece has at least one stage)
+  const unsigned long long pa = (unsigned long long)(uintptr_t)A & 0xFFFFFFFFFFFFull, pb = (unsigned long long)(uintptr_t)B & 0xFFFFFFFFFFFFull;
+  const unsigned long long rsAB2 = (unsigned long long)((unsigned)M * (unsigned)lda * 2u) | ((unsigned long long)((unsigned)N * (unsigned)ldb * 2u) << 32);
+  const unsigned long long str8 = (unsigned long long)(8u * (unsigned)lda * 2u) | ((unsigned long long)(8u * (unsigned)ldb * 2u) << 32);
+  const unsigned long long wl = (unsigned long long)((unsigned)w | (((unsigned)rowxor >> 3) << 8)) | ((unsigned long long)lds0 << 32);
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+  const unsigned voffA = (unsigned)(m0 + 64 * w + lr) * (unsigned)lda * 2u + (unsigned)lc * 16u;
+  const unsigned voffB = (unsigned)(n0 + lr) * (unsigned)ldb * 2u + (unsigned)lc * 16u;
+  const int frow = lane & 15, fkc = lane >> 4, fsw = lane & 7;
+  const unsigned ck0 = (unsigned)((fkc ^ fsw) << 4);
+  const unsigned rdA = lds0 + (unsigned)((64 * w + frow) * 128) + ck0;
+  const unsigned rdB = lds0 + (unsigned)(SA * A_STAGE) + (unsigned)(frow * 128) + ck0;
+  Ring4AsmSK::run(acc, pa, pb, rsAB2, str8, wl, (unsigned)(kel0 * 2), (unsigned)nw, voffA, voffB, rdA, rdB, xp, fa);
+}
+
 }  // namespace fvqa_ring4

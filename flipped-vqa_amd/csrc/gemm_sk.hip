@@ -22,6 +22,7 @@
 #include "gemm256_loop.h"
 #include "gemm_sk_plan.h"
 #include "gemm_skinny.h"
+#include "gemm4w_kernel.h"
 #include "probe.h"
 #include <atomic>
 #include <cstdlib>
@@ -59,7 +60,7 @@ struct SkArgs {
   SkRider rider;
   // FVQA_EPI_ROPE (the QKV projection): columns [0, rope_cols) are q | k heads of 2*rope_hp dims, row m is position m % rope_S
   const float* rope_cos; const float* rope_sin;
-  int rope_S, rope_cols, rope_hp;
+  int rope_S, rope_cols, rope_hp, rope_hmask;
 };
 
 __device__ __forceinline__ int xcd_chunk(int bid, int nwg) {     // consecutive work ids share an XCD (bijective)
@@ -539,6 +540,124 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
   }
 }
 
+
+// ---- the same partition and hand-off protocol on the 4-wave main loop (gemm4w_loop.h: one wave per SIMD, a wave = 64 rows x 256
+// columns, accumulators acc[j][4 i + e] for row block i < 4 and column block j < 16): the loop of a split piece is 7-10 % faster
+// than the 8-wave one above (W1|W3^T piece, 86 stages: 115.9 against 129.4 us; profiles/r04_gemm4w.log). Pieces: 2 or 4 per
+// tile (a wave has 4 row blocks to share out); bf16 tiles, 24-bit slabs. The WHOLE hand-off — publish, barrier, flag and
+// bounded poll, barrier, fetch-and-add in piece order — is generated assembly inside the loop's own statement (gemm4w_asm.h
+// Ring4AsmSK): with C++ anywhere between the loop and the last touch of the accumulators hipcc spilled them to scratch
+// (226-754 registers). This kernel only prepares the parameters: one register, parameter k in lane k. Slab image of a
+// workgroup: wave w at w * 64 KiB, row block i at i * 12 KiB, its 16 quads as 12 words of 1 KiB.
+template <typename TO, int EPI>
+__global__ __launch_bounds__(256) void gemm4w_sk_k(const SkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using X = fvqa_ring4::Ring4AsmSK;
+  const fvqa_sk_plan& P = a.plan;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int n_main = P.n_teams * P.ts;
+  if ((int)blockIdx.x >= n_main) {                        // rider workgroups (spread over the XCDs by the dispatcher)
+    const SkRider& r = a.rider;
+    float(*part)[8][16][20] = reinterpret_cast<float(*)[8][16][20]>(smem);
+    for (int pair = (int)blockIdx.x - n_main; pair * 32 < r.N; pair += r.n_wg) {
+      if (r.acc)
+        skinny_strip2_4w<float, FVQA_EPI_SKINNY_ACC>((const bf16_t*)r.A, (const bf16_t*)r.B, (float*)r.C, r.M, r.N, r.K, r.lda,
+                                                     r.ldb, r.ldc, pair * 32, part);
+      else
+        skinny_strip2_4w<bf16_t, FVQA_EPI_NONE>((const bf16_t*)r.A, (const bf16_t*)r.B, (bf16_t*)r.C, r.M, r.N, r.K, r.lda,
+                                                r.ldb, r.ldc, pair * 32, part);
+      __syncthreads();
+    }
+    return;
+  }
+  const int wid = xcd_chunk(blockIdx.x, n_main);
+  const int g = wid / P.ts, jm = wid - g * P.ts;
+  auto slab48 = [&](int id) { return (unsigned long long)(uintptr_t)(a.slabs + (size_t)id * SLAB_FLOATS) & 0xFFFFFFFFFFFFull; };
+  fvqa_sk_seg s;
+  for (int idx = 0; fvqa_sk_segment(P, g, idx, &s); ++idx) {
+    const int tni = s.tile / P.mgroups, mg = s.tile - tni * P.mgroups;
+    const int mt = mg * P.ts + jm;
+    if (mt >= P.tm) continue;                             // m group with fewer tiles than the team has members
+    const int m0 = mt * TM, n0 = tni * 256;
+    const int own = 4 / s.n;                              // register row blocks this piece reduces and stores
+    const int rowxor = s.n > 1 ? s.c * own * 16 : 0;
+    // exchange parameters, parameter k in lane k; partners in ascending piece order with this piece left out
+    const int team0 = g - s.c * P.pstride;                // team holding piece 0 of this tile
+    auto partner_wid = [&](int q) { const int p = q < s.c ? q : q + 1; return (team0 + p * P.pstride) * P.ts + jm; };
+    unsigned xp = 0;
+    {
+      const int k = lane;
+      const unsigned long long mine = slab48(wid), fl = (unsigned long long)(uintptr_t)(a.sync + 1 + wid),
+                               er = (unsigned long long)(uintptr_t)a.sync;
+      if (k == X::XP_NP) xp = (unsigned)s.n;
+      else if (k == X::XP_C) xp = (unsigned)s.c;
+      else if (k == X::XP_SLAB) xp = (unsigned)mine;
+      else if (k == X::XP_SLAB + 1) xp = (unsigned)(mine >> 32);
+      else if (k >= X::XP_PSLAB && k < X::XP_PSLAB + 6) {
+        const int q = (k - X::XP_PSLAB) >> 1;
+        if (q < s.n - 1) {
+          const unsigned long long b = slab48(partner_wid(q));
+          xp = (k - X::XP_PSLAB) & 1 ? (unsigned)(b >> 32) : (unsigned)b;
+        }
+      } else if (k >= X::XP_POFF && k < X::XP_POFF + 3) {
+        const int q = k - X::XP_POFF, p = q < s.c ? q : q + 1;
+        xp = (unsigned)(((s.c ^ p) * own) * 12 * 1024);   // my tile row block c*own + i sits in partner p's block ((c ^ p) * own + i)
+      } else if (k == X::XP_FLAG) xp = (unsigned)fl;
+      else if (k == X::XP_FLAG + 1) xp = (unsigned)(fl >> 32);
+      else if (k == X::XP_EPOCH) xp = (unsigned)a.epoch;
+      else if (k == X::XP_EPOCH + 1) xp = (unsigned)(a.epoch >> 32);
+      else if (k == X::XP_ERR) xp = (unsigned)er;
+      else if (k == X::XP_ERR + 1) xp = (unsigned)(er >> 32);
+      else if (k == X::XP_WOFF) xp = (unsigned)(w * 64 * 1024);
+      else if (k == X::XP_SLABBYTES) xp = (unsigned)(SLAB_FLOATS * 4);
+#ifdef FVQA_SK_CLOCK
+      const unsigned long long sa = idx == 0 ? (unsigned long long)(uintptr_t)(a.stamps + (size_t)wid * 16) : 0ull;
+      if (k == X::XP_STAMP) xp = (unsigned)sa;
+      else if (k == X::XP_STAMP + 1) xp = (unsigned)(sa >> 32);
+#endif
+    }
+    const unsigned long long fa = (unsigned long long)(uintptr_t)(a.sync + 1 + (lane < s.n - 1 ? partner_wid(lane) : wid));
+    fvqa_ring4::f32x16 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    fvqa_ring4::ring4_loop_sk(acc, lds0, (const bf16_t*)a.A, (const bf16_t*)a.B, a.M, a.N, a.lda, a.ldb, m0, n0,
+                              (size_t)s.k0 * 64, s.k1 - s.k0, w, lane, rowxor, xp, fa);
+#ifdef FVQA_SK_CLOCK
+    if (tid == 0 && idx == 0) {                           // (words 0-3 of the record: the statement's own stamps around its loop)
+      u64* st_ = a.stamps + (size_t)wid * 16;
+      st_[4] = ((u64)(unsigned)a.N << 32) | (unsigned)a.K;
+      st_[5] = a.epoch;
+      st_[6] = (u64)EPI | ((u64)s.n << 8) | ((u64)(s.k1 - s.k0) << 16) | (16ull << 32) | ((u64)sizeof(TO) << 40) | ((u64)n_main << 48);
+      st_[7] = (u64)a.M;
+    }
+#endif
+    int lane_e = lane, w_e = w, m0_e = m0, n0_e = n0;      // (see gemm_sk_256: keeps the epilogue's addressing below the loop)
+    asm volatile("" : "+v"(lane_e), "+s"(w_e), "+s"(m0_e), "+s"(n0_e));
+    fvqa_g4::store_tile4<16, TO, EPI>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);
+    __syncthreads();                                      // staging reads done before the next segment's DMA
+  }
+}
+
+template <typename TO, int EPI>
+int launch_sk4(const SkArgs& a, hipStream_t st) {
+  auto k = gemm4w_sk_k<TO, EPI>;
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done.load()) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, fvqa_ring4::Geo<16>::RING_BYTES);
+    attr_done.store(true);
+  }
+  {
+    FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (a.plan.s > 1 ? 16 : 0) | (sizeof(TO) == 4 ? 32 : 0) | 128);
+    hipLaunchKernelGGL(k, dim3(a.plan.n_teams * a.plan.ts + a.rider.n_wg), dim3(256), fvqa_ring4::Geo<16>::RING_BYTES, st, a);
+  }
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
 std::atomic<unsigned long long> g_epoch{0};
 
 template <typename T, typename TO, int EPI>
@@ -677,6 +796,16 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     a.rider = SkRider{rider->A, rider->B, rider->C, rider->M, rider->N, rider->K, rider->lda, rider->ldb, rider->ldc,
                       rider->accumulate_f32, idle < strips ? idle : strips};
     if (rode) *rode = 1;
+  }
+  // pure split launches of bf16 tiles with 24-bit slabs (2 or 4 pieces per tile: the N = 4096 outputs at M = 1024) run on the
+  // 4-wave main loop (FVQA_GEMM4W_SK=0: the 8-wave kernel, for A/B runs)
+  static const bool sk4 = !(getenv("FVQA_GEMM4W") && getenv("FVQA_GEMM4W")[0] == '0') &&
+                          !(getenv("FVQA_GEMM4W_SK") && getenv("FVQA_GEMM4W_SK")[0] == '0');
+  if (sk4 && SK_PACK24 && dtype == FVQA_BF16 && out_dtype == FVQA_BF16 && a.plan.full == 0 && a.plan.s >= 2 && a.plan.s <= 4 &&
+      (epilogue == FVQA_EPI_NONE || epilogue == FVQA_EPI_RESIDUAL) && (size_t)M * lda * 2 < 0x7fffffffull &&
+      (size_t)N * ldb * 2 < 0x7fffffffull) {
+    a.rope_hmask = 0;
+    return epilogue == FVQA_EPI_NONE ? launch_sk4<bf16_t, FVQA_EPI_NONE>(a, st) : launch_sk4<bf16_t, FVQA_EPI_RESIDUAL>(a, st);
   }
 #define SK(T, TO)                                                                             \
   switch (epilogue) {                                                                         \

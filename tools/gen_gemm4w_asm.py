@@ -31,7 +31,7 @@ SA, SB = 2, 3
 A_STAGE = 256 * 128
 
 
-def gen(NBT):
+def gen(NBT, sk=False):
     B_STAGE = 16 * NBT * 128
     PIECES_B = 2 * NBT
     NPB = (PIECES_B + 3) // 4
@@ -95,6 +95,18 @@ def gen(NBT):
 
     # ---------------- prologue
     e(f"; ---- 4-wave ring loop, NBT = {NBT}")
+    if sk:
+        # diagnostic stamps (tools/sk_clock.py): xp lanes STAMP, STAMP + 1 = address of this workgroup's record, 0 = none (the
+        # shipping build): s_memtime / s_memrealtime on both sides of the loop, stored by lane 0 of wave 0
+        e(f"v_readlane_b32 s96, %[xp], {XP['STAMP']}")
+        e(f"v_readlane_b32 s97, %[xp], {XP['STAMP'] + 1}")
+        e("s_nop 4")
+        e("s_cmp_eq_u64 s[96:97], 0")
+        e("s_cbranch_scc1 L_nostamp0_%=")
+        e("s_memtime s[98:99]")
+        e("s_memrealtime s[100:101]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("L_nostamp0_%=:")
     # packed scalar operands (an asm statement takes at most 30 operands): 64-bit pairs copied to fixed registers
     e(f"s_mov_b64 s[44:45], %[rsA01]")                            # descriptor words 0-1 (base address) of A and B
     e(f"s_mov_b64 s[48:49], %[rsB01]")
@@ -216,13 +228,56 @@ def gen(NBT):
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")                            # zero-fill DMA and unused reads of the stages past the end
     e("s_nop 15")                                                 # MFMA results -> any reader after the statement
     e("s_nop 15")
+    if sk:
+        assert NBT == 16
+        e("s_cmp_eq_u64 s[96:97], 0")
+        e("s_cbranch_scc1 L_nostamp1_%=")
+        e("s_memtime s[76:77]")
+        e("s_memrealtime s[78:79]")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_cmp_lg_u32 {S_W}, 0")
+        e("s_cbranch_scc1 L_nostamp1_%=")
+        e("s_mov_b64 s[80:81], exec")
+        e("s_mov_b64 exec, 1")
+        e("v_mov_b32 v226, s96")
+        e("v_mov_b32 v227, s97")
+        for k, r in enumerate((98, 99, 100, 101)):
+            e(f"v_mov_b32 v{228 + k}, s{r}")
+        e("global_store_dwordx4 v[226:227], v[228:231], off")
+        for k, r in enumerate((76, 77, 78, 79)):
+            e(f"v_mov_b32 v{232 + k}, s{r}")
+        e("global_store_dwordx4 v[226:227], v[232:235], off offset:16")
+        e("s_mov_b64 exec, s[80:81]")
+        e("L_nostamp1_%=:")
+        L.extend(gen_sk_tail())
 
     body = "\n".join(f'      "{ln}\\n"' for ln in L)
     accs = ", ".join(f'"+{{a[{16 * j}:{16 * j + 15}]}}"(acc[{j}])' for j in range(NBT))
     clob = ['"memory"', '"scc"', '"vcc"']
     clob += [f'"v{n}"' for n in range(64, 248)]
-    clob += [f'"s{n}"' for n in range(42, 96)]
+    clob += [f'"s{n}"' for n in range(42, 102 if sk else 96)]
     clob_s = ", ".join(clob)
+    if sk:
+        xp_enum = ", ".join(f"XP_{k} = {v}" for k, v in XP.items())
+        return f'''
+// The split-K form of the NBT = 16 loop (gemm_sk.hip gemm4w_sk_k): the loop, then — still inside the SAME statement, so that
+// the compiler never sees the accumulators between them — the exchange of the tile's pieces (generator: "split-K exchange").
+// xp: the exchange parameters, parameter k in lane k (XP_* below); fa: lane q < np - 1 = address of the epoch flag of partner q.
+struct Ring4AsmSK {{
+  enum {{ {xp_enum} }};                 // lanes of xp
+  static __device__ __forceinline__ void run(f32x16 (&acc)[{NBT}], unsigned long long rsA01, unsigned long long rsB01,
+                                             unsigned long long rsAB2, unsigned long long str8, unsigned long long wl,
+                                             unsigned kb0, unsigned nw, unsigned voffA, unsigned voffB, unsigned rdA,
+                                             unsigned rdB, unsigned xp, unsigned long long fa) {{
+    asm volatile(
+{body}
+      : {accs}
+      : [rsA01] "s"(rsA01), [rsB01] "s"(rsB01), [rsAB2] "s"(rsAB2), [str8] "s"(str8), [wl] "s"(wl), [kb0] "s"(kb0), [nw] "s"(nw),
+        [voffA] "v"(voffA), [voffB] "v"(voffB), [rdA] "v"(rdA), [rdB] "v"(rdB), [xp] "v"(xp), [fa] "v"(fa)
+      : {clob_s});
+  }}
+}};
+'''
     return f'''
 template <> struct Ring4Asm<{NBT}> {{
   // rsA01 / rsB01: base addresses (descriptor words 0-1); rsAB2: records of A | records of B << 32; str8: bytes per 8 rows of
@@ -240,6 +295,220 @@ template <> struct Ring4Asm<{NBT}> {{
   }}
 }};
 '''
+
+
+# ---- split-K exchange of the 4-wave kernel in the accumulator registers (NBT = 16; gemm_sk.hip: gemm4w_sk_k) ----------------
+# A tile cut NP ways along K: piece c has reduced... register row blocks [0, OWN) (OWN = 4 / NP) of every wave — the row
+# permutation of the loop (rowxor) puts the rows a piece owns there — and hands the blocks [OWN, 4) to its partners through its
+# slab. Slab image of a workgroup (24-bit partials, gemm_sk.hip pack24): wave w at w * 64 KiB, row block i at i * 12 KiB, the
+# 16 quads of a row block as 12 words of 1 KiB (64 lanes x 16 bytes): word 3*jg + k of column-block group jg.
+# Both passes are generated assembly for the same reason as the loop: C++ around the accumulator vectors made hipcc spill to
+# scratch (360-520 bytes per lane), and a kernel with scratch pays at every launch boundary of the step.
+XP = dict(NP=0, C=1, SLAB=2, PSLAB=4, POFF=10, FLAG=13, EPOCH=15, ERR=17, WOFF=19, SLABBYTES=20, STAMP=21)   # lanes of the xp operand
+V_XOFF = "v224"                                                  # per-lane slab offset: w * 64 KiB + lane * 16
+
+
+def gen_publish(NP):
+    """row blocks [OWN, 4) of the accumulators -> this workgroup's slab (descriptor s[44:47]), 24-bit packed"""
+    OWN = 4 // NP
+    L = []
+    e = L.append
+    e(f"; ---- publish row blocks [{OWN}, 4) of a split-K piece ({NP} pieces)")
+    cnt = 0
+    for i in range(OWN, 4):
+        for jg in range(4):
+            O = 96 + 16 * (cnt & 1)
+            cnt += 1
+            for jj in range(4):
+                for el in range(4):
+                    e(f"v_accvgpr_read_b32 v{64 + 4 * jj + el}, a{16 * (4 * jg + jj) + 4 * i + el}")
+            for idx in range(16):                       # round to 24 bits unless the exponent is all ones (pack24 / round24)
+                u = f"v{64 + idx}"
+                e(f"v_and_b32 v80, s48, {u}")
+                e(f"v_add_u32 v81, 0x80, {u}")
+                e("v_cmp_ne_u32 vcc, s48, v80")
+                e(f"v_cndmask_b32 {u}, {u}, v81, vcc")
+            for jj in range(4):
+                u0, u1, u2, u3 = (f"v{64 + 4 * jj + k}" for k in range(4))
+                e(f"v_perm_b32 v{O + 3 * jj}, {u0}, {u3}, s49")
+                e(f"v_perm_b32 v{O + 3 * jj + 1}, {u1}, {u3}, s50")
+                e(f"v_perm_b32 v{O + 3 * jj + 2}, {u2}, {u3}, s51")
+            e(f"s_mov_b32 s52, {(i * 12 + jg * 3) * 1024}")
+            for k in range(3):
+                off = f" offset:{k * 1024}" if k else ""
+                e(f"buffer_store_dwordx4 v[{O + 4 * k}:{O + 4 * k + 3}], {V_XOFF}, s[44:47], s52 offen{off} sc1")
+    return L
+
+
+def gen_reduce(NP, C):
+    """piece C of NP: partner q's descriptor in s[44+4q : 47+4q], its block-group offset in s[72+q]"""
+    OWN = 4 // NP
+    L = []
+    e = L.append
+    e(f"; ---- piece {C} of {NP}: fetch the partners' partials of row blocks [0, {OWN}) and add them in piece order")
+    reg = 64
+    where = {}
+    for i in range(OWN):
+        for jg in range(4):
+            for q in range(NP - 1):
+                e(f"s_add_u32 s56, s{72 + q}, {(i * 12 + jg * 3) * 1024}")
+                where[(i, jg, q)] = reg
+                for k in range(3):
+                    off = f" offset:{k * 1024}" if k else ""
+                    e(f"buffer_load_dwordx4 v[{reg}:{reg + 3}], {V_XOFF}, s[{44 + 4 * q}:{47 + 4 * q}], s56 offen{off} sc1")
+                    reg += 4
+    assert reg <= 208
+    e("s_mov_b32 s57, 0xFFFFFF00")
+    e("s_mov_b32 s58, 0x04000C0C")
+    e("s_mov_b32 s59, 0x0706000C")
+    e("s_waitcnt vmcnt(0)")
+    order = [("own", None) if pce == C else ("q", pce if pce < C else pce - 1) for pce in range(NP)]
+
+    def unpack(base, jj, dst):
+        """quad jj of a 12-register packed group at v[base..] -> 4 floats in v[dst..dst+3] (unpack24)"""
+        d0, d1, d2 = (f"v{base + 3 * jj + k}" for k in range(3))
+        e(f"v_perm_b32 v{dst + 3}, {d0}, {d1}, s58")
+        e(f"v_perm_b32 v{dst + 3}, v{dst + 3}, {d2}, s59")
+        e(f"v_and_b32 v{dst}, s57, {d0}")
+        e(f"v_and_b32 v{dst + 1}, s57, {d1}")
+        e(f"v_and_b32 v{dst + 2}, s57, {d2}")
+
+    for i in range(OWN):
+        for jg in range(4):
+            for jj in range(4):
+                a0 = 16 * (4 * jg + jj) + 4 * i
+                for el in range(4):
+                    e(f"v_accvgpr_read_b32 v{208 + el}, a{a0 + el}")
+                first = True
+                for kind, q in order:
+                    if kind == "own":
+                        src = 208
+                    else:
+                        src = 212
+                        unpack(where[(i, jg, q)], jj, 212)
+                    if first:
+                        for el in range(4):
+                            e(f"v_mov_b32 v{216 + el}, v{src + el}")
+                        first = False
+                    else:
+                        for el in range(4):
+                            e(f"v_add_f32 v{216 + el}, v{216 + el}, v{src + el}")
+                for el in range(4):
+                    e(f"v_accvgpr_write_b32 a{a0 + el}, v{216 + el}")
+    return L
+
+
+def gen_sk_tail():
+    """after the loop, inside the same statement: publish -> barrier -> flag / poll (wave 0) -> barrier -> fetch and add.
+    np == 1 (a whole tile): one barrier (every wave is done reading the ring), nothing else."""
+    L = []
+    e = L.append
+
+    def lane(dst, k):
+        e(f"v_readlane_b32 {dst}, %[xp], {k}")
+
+    e("; ---- split-K exchange")
+    lane("s60", XP["NP"])
+    lane("s61", XP["C"])
+    for k in range(2):
+        lane(f"s{44 + k}", XP["SLAB"] + k)
+    lane("s46", XP["SLABBYTES"])
+    lane("s62", XP["WOFF"])
+    for q in range(3):
+        lane(f"s{72 + q}", XP["POFF"] + q)
+    for k in range(2):
+        lane(f"s{66 + k}", XP["EPOCH"] + k)
+        lane(f"s{68 + k}", XP["FLAG"] + k)
+    e("s_mov_b32 s47, 0x00020000")
+    e("v_mbcnt_lo_u32_b32 v224, -1, 0")
+    e("v_mbcnt_hi_u32_b32 v224, -1, v224")
+    e("v_lshlrev_b32 v224, 4, v224")
+    e("s_nop 4")                                        # (v_readlane results -> scalar / memory instructions)
+    e(f"v_add_u32 {V_XOFF}, s62, v224")
+    e("s_cmp_lt_u32 s60, 2")
+    e("s_cbranch_scc0 L_xchg_%=")
+    e("s_barrier")
+    e("s_branch L_xdone_%=")
+    e("L_xchg_%=:")
+    e("s_mov_b32 s48, 0x7F800000")
+    e("s_mov_b32 s49, 0x07060503")
+    e("s_mov_b32 s50, 0x07060502")
+    e("s_mov_b32 s51, 0x07060501")
+    e("s_cmp_eq_u32 s60, 2")
+    e("s_cbranch_scc1 L_pub2_%=")
+    L.extend(gen_publish(4))
+    e("s_branch L_pubdone_%=")
+    e("L_pub2_%=:")
+    L.extend(gen_publish(2))
+    e("L_pubdone_%=:")
+    e("s_waitcnt vmcnt(0)")                             # EVERY storing wave drains its write-through stores
+    e("s_barrier")
+    # wave 0: raise this workgroup's flag (lane 0), then lanes 0 .. np-2 poll one partner's flag each (bounded)
+    e("s_cmp_lg_u32 s62, 0")
+    e("s_cbranch_scc1 L_flagdone_%=")
+    e("s_mov_b64 s[64:65], exec")
+    e("v_mov_b32 v226, s66")
+    e("v_mov_b32 v227, s67")
+    e("v_mov_b32 v228, s68")
+    e("v_mov_b32 v229, s69")
+    e("s_mov_b64 exec, 1")
+    e("global_store_dwordx2 v[228:229], v[226:227], off sc1")
+    e("s_sub_u32 s70, s60, 1")
+    e("s_bfm_b64 exec, s70, 0")
+    e("s_mov_b32 s71, 0")
+    e("L_poll_%=:")
+    e("global_load_dwordx2 v[230:231], %[fa], off sc1")
+    e("s_waitcnt vmcnt(0)")
+    e("v_cmp_ne_u64 vcc, v[226:227], v[230:231]")
+    e("s_cmp_eq_u64 vcc, 0")
+    e("s_cbranch_scc1 L_polled_%=")
+    e("s_sleep 8")
+    e("s_add_u32 s71, s71, 1")
+    e("s_cmp_lt_u32 s71, 0x400000")
+    e("s_cbranch_scc1 L_poll_%=")
+    lane("s68", XP["ERR"])                              # a lost partner: raise the error word and go on
+    lane("s69", XP["ERR"] + 1)
+    e("s_mov_b64 exec, 1")
+    e("s_nop 4")
+    e("v_mov_b32 v228, s68")
+    e("v_mov_b32 v229, s69")
+    e("v_mov_b32 v232, 1")
+    e("v_mov_b32 v233, 0")
+    e("global_atomic_or_x2 v[228:229], v[232:233], off")
+    e("s_waitcnt vmcnt(0)")
+    e("L_polled_%=:")
+    e("s_mov_b64 exec, s[64:65]")
+    e("L_flagdone_%=:")
+    e("s_barrier")
+    # partner descriptors: base of partner q in xp lanes PSLAB + 2q, +1
+    for q in range(3):
+        for k in range(2):
+            lane(f"s{44 + 4 * q + k}", XP["PSLAB"] + 2 * q + k)
+        if q:
+            e(f"s_mov_b32 s{46 + 4 * q}, s46")
+            e(f"s_mov_b32 s{47 + 4 * q}, s47")
+    e("s_nop 4")
+    e("s_cmp_eq_u32 s60, 2")
+    e("s_cbranch_scc1 L_red2_%=")
+    for c in range(4):
+        if c < 3:
+            e(f"s_cmp_eq_u32 s61, {c}")
+            e(f"s_cbranch_scc0 L_red4n{c}_%=")
+        L.extend(gen_reduce(4, c))
+        e("s_branch L_reddone_%=")
+        if c < 3:
+            e(f"L_red4n{c}_%=:")
+    e("L_red2_%=:")
+    e("s_cmp_eq_u32 s61, 0")
+    e("s_cbranch_scc0 L_red2n_%=")
+    L.extend(gen_reduce(2, 0))
+    e("s_branch L_reddone_%=")
+    e("L_red2n_%=:")
+    L.extend(gen_reduce(2, 1))
+    e("L_reddone_%=:")
+    e("s_nop 4")
+    e("L_xdone_%=:")
+    return L
 
 
 HEADER = '''// GENERATED by tools/gen_gemm4w_asm.py — do not edit; edit the generator and re-run it.
@@ -264,5 +533,7 @@ if __name__ == "__main__":
         f.write(HEADER)
         for n in widths:
             f.write(gen(n))
+        if 16 in widths:
+            f.write(gen(16, sk=True))
         f.write("\n}  // namespace fvqa_ring4\n")
     print(out)

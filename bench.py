@@ -487,12 +487,12 @@ def main():
                 from fvqa import build as fbuild
                 if pm.get("source_hash") == fbuild.source_hash():
                     w_ = [(v["launches_sampled"], v["hbm_bytes_per_launch"]) for k, v in pm.get("kernels", {}).items()
-                          if (k.startswith("gemm_sk_256") or "gemm4w_k" in k) and "hbm_bytes_per_launch" in v]
+                          if (k.startswith("gemm_sk_256") or "gemm4w_k" in k or "gemm4w_sk_k" in k) and "hbm_bytes_per_launch" in v]
                     if w_:
                         traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
                         tsrc = f"profiles/{os.path.basename(tj)} (kernel sources {pm['source_hash'][:12]}, same workload)"
             roof = {"bound": "mfma",
-                    "kernel": "projection GEMMs of the step, every launch of every instantiation: gemm4w_k (4-wave whole-tile kernel, one wave per SIMD, tile width per problem: *_4w) and gemm_sk_256 (persistent 256x256-tile split-K kernel, reduced in the launch: *_splitk)",
+                    "kernel": "projection GEMMs of the step, every launch of every instantiation, all on the one-wave-per-SIMD main loop: gemm4w_k (whole tiles, tile width per problem: *_4w) and gemm4w_sk_k (256x256 tiles cut 2 or 4 ways along K, reduced inside the launch: *_splitk_4w)",
                     "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_source": tsrc,
                     "method": f"HIP events around every {stride_used}th launch in a repeat of the timed steps "

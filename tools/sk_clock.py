@@ -141,7 +141,7 @@ def mode_step(seconds):
     ws = ops.gemm_workspace(dev, need)
     st = read_ring(ws, need)
     last = int(st[:, :, 5].max())
-    summarise(st, last - 257, "C2 step, last 258 launches (gemm_sk_256: split 2/4; gemm4w_k: split 1, first tile of a workgroup)")
+    summarise(st, last - 257, "C2 step, last 258 launches (gemm4w_sk_k or gemm_sk_256: split 2/4; gemm4w_k: split 1, first tile of a workgroup)")
 
 
 def mode_b2b(seconds):

@@ -470,6 +470,56 @@ def attn_decode(qkv_row, qkv_cache, o_row, gate1, gate2, vstart, pos, rope, n_se
     return o_row
 
 
+DECODE_PTRS = 9
+
+
+def decode_token_ok(n_seq, S, H, Dh, Hf, A, dtype) -> bool:
+    """True when fvqa_decode_token (one persistent launch per generated token) serves this shape."""
+    return bool(_lib.load().fvqa_decode_token_ok(n_seq, S, H, Dh, Hf, A, dt_code(dtype)))
+
+
+def decode_persistent_enabled() -> bool:
+    """The persistent per-token launch is exact but measured slower than the per-kernel token loop (csrc/decode.hip): opt-in."""
+    import os
+    return os.environ.get("FVQA_DECODE_PERSISTENT", "0") == "1"
+
+
+def decode_scratch(n_layers, n_seq, H, Dh, Hf, device) -> torch.Tensor:
+    """Scratch of fvqa_decode_token: one set of row buffers per layer + every workgroup's private normalised rows."""
+    n = int(_lib.load().fvqa_decode_scratch_bytes(n_layers, n_seq, H, Dh, Hf))
+    return torch.empty(n + 256, dtype=torch.uint8, device=device)
+
+
+def decode_workspace(device) -> torch.Tensor:
+    return torch.zeros(int(_lib.load().fvqa_decode_workspace()), dtype=torch.uint8, device=device)
+
+
+def decode_token(table, n_layers, x, x_out, scratch, vstart, pos, rope, n_seq, S, H, Dh, Hf, A, F, eps, cache_rotated: bool, ws):
+    """All layers of one generated token in one launch (csrc/decode.hip). table: int64 device tensor (n_layers, DECODE_PTRS)
+    of addresses; x (n_seq, D): the new rows, x_out (n_seq, D): the last layer's output rows. The error word of `ws` (byte 16)
+    is nonzero after the launch if a grid barrier timed out — generate.greedy_decode reads it back with the ids."""
+    _dev(table, x, x_out, scratch, vstart, pos, ws)
+    D = H * Dh
+    cos_t, sin_t = _rope_tables(rope, S, Dh, "decode_token")
+    _need(cos_t is not None, "decode_token: rope tables")
+    _need(table.dtype == torch.int64 and tuple(table.shape) == (n_layers, DECODE_PTRS) and table.is_contiguous(),
+          "decode_token: table")
+    for t in (x, x_out):
+        _need(t.dtype == torch.bfloat16 and tuple(t.shape) == (n_seq, D) and t.is_contiguous(), "decode_token: x / x_out")
+    _need(x.data_ptr() != x_out.data_ptr(), "decode_token: x_out must not be x")
+    _need(scratch.dtype == torch.uint8, "decode_token: scratch")
+    off = (-scratch.data_ptr()) % 256                      # the library wants 256-byte alignment
+    nbytes = scratch.numel() - off
+    _need(pos.dtype == torch.int64 and pos.numel() == n_seq, "decode_token: pos")
+    _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "decode_token: vstart")
+    _need(ws.numel() * ws.element_size() >= int(_lib.load().fvqa_decode_workspace()), "decode_token: workspace")
+    rc = _lib.load().fvqa_decode_token(_ptr(table), n_layers, _ptr(x), _ptr(x_out), scratch.data_ptr() + off, nbytes,
+                                       _ptr(vstart), _ptr(pos), _ptr(cos_t), _ptr(sin_t), n_seq, S, H, Dh, Hf, A, F,
+                                       float(eps), 1 if cache_rotated else 0, _ptr(ws), dt_code(x.dtype), _stream())
+    _lib.check(rc, "fvqa_decode_token")
+    return x_out
+
+
 def attn_bwd_workspace(n_seq, S, H, Dh, A) -> int:
     return int(_lib.load().fvqa_attn_bwd_workspace(n_seq, S, H, Dh, A))
 

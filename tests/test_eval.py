@@ -97,6 +97,22 @@ def test_bf16_generation_is_pinned_in_both_rope_modes(rope_in_gemm):
 
 
 @pytest.mark.gpu
+def test_bf16_generation_with_the_persistent_token_kernel(monkeypatch):
+    """FVQA_DECODE_PERSISTENT=1: every generated token runs all layers in ONE persistent launch (csrc/decode.hip; opt-in, measured
+    slower than the per-kernel token loop). Same arithmetic, so the bf16 build still reproduces the reference's 31 x 4 tokens,
+    similarities and decided options on the peaked 7B-width fixture."""
+    from fvqa import ops
+    assert ops.decode_token_ok(4, 128, 32, 128, 11008, 10, torch.bfloat16)
+    monkeypatch.setenv("FVQA_DECODE_PERSISTENT", "1")
+    assert ops.decode_persistent_enabled()
+    calls = []
+    real = ops.decode_token
+    monkeypatch.setattr(ops, "decode_token", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    test_generation_matches_reference(torch.bfloat16, "7b_l2_peaked")
+    assert len(calls) == 31                                   # one launch per generated token
+
+
+@pytest.mark.gpu
 def test_val_one_epoch_with_the_model_reports_the_references_accuracy(tmp_path):
     """engine.val_one_epoch driving the real model (fp32 build, 7B width) over the reference's validation batch: accuracy and
     per-type meters are those of the reference's own choices (fixture), the answers file is written per batch."""

@@ -855,3 +855,77 @@ def test_set_error_word_skips_the_optimizer_step_and_raises():
         word.view(torch.int64)[0] = 0
     step()
     assert scaler._found.item() == 0.0 and not torch.equal(flat.flat, p1)
+
+
+# ------------------------------------------------------------------------------ one generated token, all layers in one launch
+def _ab16_rows(w1, w3):
+    """W1 | W3 in the engine's AB16 row order: blocks of 16 W1 rows and 16 W3 rows alternate (fvqa/step.py pack)."""
+    Hf, D = w1.shape
+    return torch.stack([w1.view(Hf // 16, 16, D), w3.view(Hf // 16, 16, D)], dim=1).reshape(2 * Hf, D).contiguous()
+
+
+@pytest.mark.parametrize("B,S,H,Hf,L,pos", [(3, 64, 4, 768, 2, [63, 5, 30]), (8, 128, 2, 1280, 3, [127, 0, 64, 9, 100, 33, 2, 77]),
+                                            (16, 40, 2, 512, 1, list(range(20, 36)))])
+def test_decode_token_equals_the_per_kernel_sequence(B, S, H, Hf, L, pos):
+    """fvqa_decode_token (csrc/decode.hip: every layer of one generated token in ONE persistent launch, grid barriers between
+    the phases) against the sequence of stand-alone kernels fvqa/generate.py issues otherwise — rmsnorm_fwd, gemm_nt (M <= 16),
+    attn_decode, swiglu_fwd: the rows after the last layer and every layer's cache (the new tokens' k, v included)
+    must be BITWISE equal (same arithmetic, same order); reference llama/model.py:428-470 at the new rows."""
+    dt = torch.bfloat16
+    Dh, A, F = 128, 10, 10
+    D = H * Dh
+    if not ops.decode_token_ok(B, S, H, Dh, Hf, A, dt):
+        pytest.skip("shape not served by the persistent token kernel")
+    cos, sin = ref_cpu.rope_tables(2 * S, Dh, torch.float32)
+    rope = (dev(cos), dev(sin))
+    layers = []
+    for i in range(L):
+        sd = 100 * i
+        w1, w3 = rnd(Hf, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 4), rnd(Hf, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 5)
+        layers.append(dict(
+            an=dev(rnd(D, dtype=dt, seed=sd + 1) + 1), wqkv=dev(rnd(3 * D, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 2)),
+            wo=dev(rnd(D, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 3)), fn=dev(rnd(D, dtype=dt, seed=sd + 6) + 1),
+            w13=dev(_ab16_rows(w1, w3)), w2=dev(rnd(D, Hf, dtype=dt, scale=1 / math.sqrt(Hf), seed=sd + 7)),
+            cache=rnd(B * S + A, 3 * D, dtype=dt, seed=sd + 8),
+            g1=dev(rnd(H, seed=sd + 9)), g2=dev(rnd(H, seed=sd + 10))))
+    x0 = rnd(B, D, dtype=dt, seed=77)
+    pos_t = dev(torch.tensor(pos, dtype=torch.int64))
+    vs = dev(torch.tensor([(7 if n % 3 else -1) for n in range(B)], dtype=torch.int32))
+    e = lambda *s: torch.empty(*s, dtype=dt, device=DEV)  # noqa: E731
+
+    def per_kernel():
+        caches = [dev(l["cache"]) for l in layers]
+        x, x2 = dev(x0), e(B, D)
+        xn, hn, h, o_row, qkv_row, ab, z = e(B, D), e(B, D), e(B, D), e(B, D), e(B, 3 * D), e(B, 2 * Hf), e(B, Hf)
+        for l, c in zip(layers, caches):
+            ops.rmsnorm_fwd(x, l["an"], xn, None, 1e-5, rows=B)
+            ops.gemm_nt(xn, l["wqkv"], qkv_row)
+            ops.attn_decode(qkv_row, c, o_row, l["g1"], l["g2"], vs, pos_t, rope, B, S, H, Dh, A, F, cache_rotated=True)
+            ops.gemm_nt(o_row, l["wo"], h, residual=x)
+            ops.rmsnorm_fwd(h, l["fn"], hn, None, 1e-5, rows=B)
+            ops.gemm_nt(hn, l["w13"], ab)
+            ops.swiglu_fwd(ab, z, B, Hf)
+            ops.gemm_nt(z, l["w2"], x2, residual=h)
+            x, x2 = x2, x
+        return x.cpu(), [c.cpu() for c in caches]
+
+    def persistent():
+        caches = [dev(l["cache"]) for l in layers]
+        table = torch.tensor([[l[k].data_ptr() for k in ("an", "wqkv", "wo", "fn", "w13", "w2")] + [c.data_ptr(), l["g1"].data_ptr(),
+                              l["g2"].data_ptr()] for l, c in zip(layers, caches)], dtype=torch.int64, device=DEV)
+        x, x_out = dev(x0), e(B, D)
+        scratch = ops.decode_scratch(L, B, H, Dh, Hf, DEV)
+        ws = ops.decode_workspace(DEV)
+        ops.decode_token(table, L, x, x_out, scratch, vs, pos_t, rope, B, S, H, Dh, Hf, A, F, 1e-5, True, ws)
+        torch.cuda.synchronize()
+        assert int(ws[16:24].view(torch.int64)[0].item()) == 0, "a grid barrier timed out"
+        assert torch.equal(x.cpu().view(torch.int16), x0.view(torch.int16))      # the input rows are read only
+        return x_out.cpu(), [c.cpu() for c in caches]
+
+    want, got = per_kernel(), persistent()
+    assert torch.isfinite(want[0].float()).all()
+    assert torch.equal(got[0].view(torch.int16), want[0].view(torch.int16))
+    for a, b in zip(got[1], want[1]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    again = persistent()
+    assert torch.equal(again[0].view(torch.int16), got[0].view(torch.int16))

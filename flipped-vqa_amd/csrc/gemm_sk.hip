@@ -358,8 +358,8 @@ __device__ __forceinline__ f32x4 unpack24(unsigned d0, unsigned d1, unsigned d2)
 }
 
 template <int NP, bool PACK>
-__device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs& a, int wid, int c, int team0, int jm,
-                                                int w, int lane, int tid, int pstride) {
+__device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs& a, int wid, int c, int g, int jm,
+                                                int w, int lane, int tid) {
   constexpr int OWN = 8 / NP;
   constexpr int WPB = PACK ? 3 : 4;                       // 16-byte words per lane per row block in a slab
   const unsigned lane_off = (unsigned)(w * 32 * 1024 + lane * 16);   // this lane's 16 bytes of word 0 of block 0 in a slab
@@ -392,7 +392,7 @@ __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs
   if (tid < NP - 1) {                   // lanes 0 .. NP-2 of wave 0: one partner's flag each, polled side by side
     if (tid == 0) __hip_atomic_store(a.sync + 1 + wid, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int p = tid < c ? tid : tid + 1;                // (a lost partner raises the error word after its bounded wait)
-    (void)wait_epoch(a.sync + 1 + (team0 + p * pstride) * ts + jm, a.epoch, a.sync);
+    (void)wait_epoch(a.sync + 1 + fvqa_sk_piece_team(a.plan, g, c, p) * ts + jm, a.epoch, a.sync);
 #ifdef FVQA_SK_ACQUIRE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // not needed while EVERY load of a partner's slab is an sc1 load
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -406,7 +406,7 @@ __device__ __forceinline__ void exchange_reduce(f32x4 (&acc)[8][4], const SkArgs
 #pragma unroll
   for (int q = 0; q < NP - 1; ++q) {
     const int p = q < c ? q : q + 1;                      // partner piece
-    const float* sl = a.slabs + (size_t)((team0 + p * pstride) * ts + jm) * SLAB_FLOATS;
+    const float* sl = a.slabs + (size_t)(fvqa_sk_piece_team(a.plan, g, c, p) * ts + jm) * SLAB_FLOATS;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sl), 0, SLAB_FLOATS * 4, 0x00020000);
     // my tile row block c*OWN + i sits in partner p's register block ((c ^ p) * OWN + i)
     const unsigned boff = lane_off + (unsigned)(((c ^ p) * OWN) * WPB * 1024);
@@ -519,11 +519,10 @@ __global__ __launch_bounds__(512) void gemm_sk_256(const SkArgs a) {
     const int tid_e = w_e * 64 + lane_e;
     if (s.n == 1) __syncthreads();                        // every wave is done reading the ring
     else {
-      const int team0 = g - s.c * P.pstride;              // team holding piece 0 of this tile
       constexpr bool PK = SK_PACK24 && sizeof(TO) == 2;  // tiles rounded to bf16 at the store: 24-bit slabs
-      if (s.n == 2) exchange_reduce<2, PK>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
-      else if (s.n == 4) exchange_reduce<4, PK>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
-      else exchange_reduce<8, PK>(acc, a, wid, s.c, team0, jm, w_e, lane_e, tid_e, P.pstride);
+      if (s.n == 2) exchange_reduce<2, PK>(acc, a, wid, s.c, g, jm, w_e, lane_e, tid_e);
+      else if (s.n == 4) exchange_reduce<4, PK>(acc, a, wid, s.c, g, jm, w_e, lane_e, tid_e);
+      else exchange_reduce<8, PK>(acc, a, wid, s.c, g, jm, w_e, lane_e, tid_e);
     }
     SK_STAMP(4);
     if constexpr (EPI == FVQA_EPI_SWIGLU_FWD) {
@@ -584,8 +583,7 @@ __global__ __launch_bounds__(256) void gemm4w_sk_k(const SkArgs a) {
     const int own = 4 / s.n;                              // register row blocks this piece reduces and stores
     const int rowxor = s.n > 1 ? s.c * own * 16 : 0;
     // exchange parameters, parameter k in lane k; partners in ascending piece order with this piece left out
-    const int team0 = g - s.c * P.pstride;                // team holding piece 0 of this tile
-    auto partner_wid = [&](int q) { const int p = q < s.c ? q : q + 1; return (team0 + p * P.pstride) * P.ts + jm; };
+    auto partner_wid = [&](int q) { const int p = q < s.c ? q : q + 1; return fvqa_sk_piece_team(P, g, s.c, p) * P.ts + jm; };
     unsigned xp = 0;
     {
       const int k = lane;
@@ -639,6 +637,9 @@ __global__ __launch_bounds__(256) void gemm4w_sk_k(const SkArgs a) {
     asm volatile("" : "+v"(lane_e), "+s"(w_e), "+s"(m0_e), "+s"(n0_e));
     fvqa_g4::store_tile4<16, TO, EPI>(acc, smem, a, m0_e, n0_e, w_e, lane_e, own, rowxor);
     __syncthreads();                                      // staging reads done before the next segment's DMA
+#ifdef FVQA_SK_CLOCK
+    if (tid == 0 && idx == 0) (a.stamps + (size_t)wid * 16)[14] = __builtin_amdgcn_s_memrealtime();   // tile stored
+#endif
   }
 }
 

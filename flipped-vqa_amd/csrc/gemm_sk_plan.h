@@ -44,16 +44,29 @@ struct fvqa_sk_plan {
   int32_t full;          // rounds of whole tiles
   int32_t rem;           // tiles of the last, split round
   int32_t s;             // pieces per tile of the last round
-  int32_t pstride;       // team distance between consecutive pieces of a tile (piece p of a tile: team0 + p * pstride)
+  int32_t pstride;       // 1: the pieces of a tile on consecutive teams; > 1: teams per XCD chunk, piece index constant per chunk (fvqa_sk_piece_team)
 };
 
 struct fvqa_sk_seg {
   int32_t tile;          // tile index in walk order: n tile = tile / mgroups, m group = tile % mgroups
   int32_t k0, k1;        // wide stages [k0, k1) of the tile's K range
-  int32_t n, c;          // piece c of n; piece p of the tile is held by team g + (p - c) * pstride
+  int32_t n, c;          // piece c of n; piece p of the tile is held by team fvqa_sk_piece_team(plan, g, c, p)
 };
 
 FVQA_HD int fvqa_sk_tiles(const fvqa_sk_plan& p) { return p.mgroups * p.tn; }
+
+// pstride > 1 (piece index constant per XCD chunk): which piece the chunks x = 0 .. s-1 of a group of s chunks hold. A 4-way
+// split puts pieces 0, 2, 1, 3 on chunks 0, 1, 2, 3 (a self-inverse swap of the middle two): measured on the MI355X
+// (profiles/r04_clock.log, per-XCD loop times on four boxes) the odd XCDs run ~4 % slower (lower clock under this load) and
+// the pieces over the FIRST half of K stream slower on the long-K shapes (W1|W3^T, W2: +3..7 %); with the identity map the
+// slow piece 1 sat on the slow XCDs 1 and 5 and every tile waited 6-9 us for it; this way the slow pieces run on the fast XCDs.
+FVQA_HD int fvqa_sk_chunk_piece(const fvqa_sk_plan& p, int x) { return p.s == 4 ? ((x == 1 || x == 2) ? 3 - x : x) : x; }
+// team that holds piece `piece` of the tile whose piece c is held by team g
+FVQA_HD int fvqa_sk_piece_team(const fvqa_sk_plan& p, int g, int c, int piece) {
+  if (p.pstride == 1) return g + (piece - c);
+  const int x = g / p.pstride, y = g - x * p.pstride;
+  return ((x / p.s) * p.s + fvqa_sk_chunk_piece(p, piece)) * p.pstride + y;        // (the chunk map is its own inverse)
+}
 
 // Segment number idx (0, 1, ...) of team g; false when the team has no such segment.
 FVQA_HD bool fvqa_sk_segment(const fvqa_sk_plan& p, int g, int idx, fvqa_sk_seg* s) {
@@ -67,7 +80,7 @@ FVQA_HD bool fvqa_sk_segment(const fvqa_sk_plan& p, int g, int idx, fvqa_sk_seg*
     r = g / p.s; c = g - r * p.s;
   } else {                                                          // piece index constant per XCD (see make_plan)
     const int x = g / p.pstride, y = g - x * p.pstride;
-    c = x % p.s; r = (x / p.s) * p.pstride + y;
+    c = fvqa_sk_chunk_piece(p, x % p.s); r = (x / p.s) * p.pstride + y;
   }
   const int qq = p.gpt / p.s, rr = p.gpt - qq * p.s;               // granules per piece, first rr pieces one more
   const int g0 = c * qq + (c < rr ? c : rr), g1 = g0 + qq + (c < rr ? 1 : 0);

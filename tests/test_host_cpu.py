@@ -249,7 +249,7 @@ def _sk_plan(M, N, K, dtype, n_cu=256):
     (2048, 2048, 2048, 1), (1024, 4096, 4096, 0), (4096, 4096, 4096, 1), (8192, 8192, 8192, 1), (256, 4096, 4096, 1)])
 def test_persistent_gemm_partition_covers_every_tile_once(M, N, K, dtype):
     """The (tile, K range) partition of csrc/gemm_sk_plan.h, walked through the host-only C entry: every wide stage of
-    every tile is computed exactly once; a split tile has 2, 4 or 8 pieces in K order held by teams `pstride` apart as
+    every tile is computed exactly once; a split tile has 2, 4 or 8 pieces in K order held by different teams as
     their LAST segment after the same number of whole tiles (partners finish together; nobody waits on a workgroup
     that still has other work to do first); with pstride > 1 all teams of an XCD chunk hold the same piece index."""
     for n_cu in (256, 304, 64):
@@ -274,10 +274,20 @@ def test_persistent_gemm_partition_covers_every_tile_once(M, N, K, dtype):
             for c, s in enumerate(ss):
                 assert s["n"] == n and s["c"] == c
                 if n > 1:
-                    assert s["team"] == ss[0]["team"] + c * p["pstride"] and s["order"] == p["full"] == n_seg[s["team"]] - 1
+                    assert s["order"] == p["full"] == n_seg[s["team"]] - 1
                     assert s["k1"] - s["k0"] > p["gran"]
-                    if p["pstride"] > 1:
-                        assert s["c"] == (s["team"] // p["pstride"]) % n
+                    if p["pstride"] == 1:
+                        assert s["team"] == ss[0]["team"] + c
+                    else:
+                        # one piece index per XCD chunk of `pstride` teams; a 4-way split holds pieces 0, 2, 1, 3 on the chunks
+                        # 0, 1, 2, 3 of a group (the slow first-half-of-K pieces on the fast even XCDs, gemm_sk_plan.h)
+                        chunk, y = divmod(s["team"], p["pstride"])
+                        want = {0: 0, 1: 2, 2: 1, 3: 3}[chunk % 4] if n == 4 else chunk % n
+                        assert s["c"] == want
+                        c0, y0 = divmod(ss[0]["team"], p["pstride"])
+                        assert y == y0 and chunk // n == c0 // n                 # same slot of the same group of chunks
+            if n > 1 and p["pstride"] > 1:
+                assert len({s["team"] // p["pstride"] for s in ss}) == n            # the pieces sit on n different chunks
 
 
 def test_persistent_gemm_plans_of_the_c2_step():

@@ -95,18 +95,6 @@ def gen(NBT, sk=False):
 
     # ---------------- prologue
     e(f"; ---- 4-wave ring loop, NBT = {NBT}")
-    if sk:
-        # diagnostic stamps (tools/sk_clock.py): xp lanes STAMP, STAMP + 1 = address of this workgroup's record, 0 = none (the
-        # shipping build): s_memtime / s_memrealtime on both sides of the loop, stored by lane 0 of wave 0
-        e(f"v_readlane_b32 s96, %[xp], {XP['STAMP']}")
-        e(f"v_readlane_b32 s97, %[xp], {XP['STAMP'] + 1}")
-        e("s_nop 4")
-        e("s_cmp_eq_u64 s[96:97], 0")
-        e("s_cbranch_scc1 L_nostamp0_%=")
-        e("s_memtime s[98:99]")
-        e("s_memrealtime s[100:101]")
-        e("s_waitcnt lgkmcnt(0)")
-        e("L_nostamp0_%=:")
     # packed scalar operands (an asm statement takes at most 30 operands): 64-bit pairs copied to fixed registers
     e(f"s_mov_b64 s[44:45], %[rsA01]")                            # descriptor words 0-1 (base address) of A and B
     e(f"s_mov_b64 s[48:49], %[rsB01]")
@@ -119,6 +107,31 @@ def gen(NBT, sk=False):
     e(f"s_mov_b32 s51, 0x00020000")
     S_W, S_RX8, S_LDS0, S_STRA8, S_STRB8 = "s42", "s43", "s59", "s56", "s57"
     e(f"s_and_b32 {S_W}, s58, 0xff")
+    if sk:
+        # diagnostic stamps (tools/sk_clock.py): xp lanes STAMP, STAMP + 1 = address of this workgroup's record, 0 = none (the
+        # shipping build): s_memtime / s_memrealtime on both sides of the loop, stored by lane 0 of wave 0
+        e(f"v_readlane_b32 s96, %[xp], {XP['STAMP']}")
+        e(f"v_readlane_b32 s97, %[xp], {XP['STAMP'] + 1}")
+        e("s_nop 4")
+        e("s_cmp_eq_u64 s[96:97], 0")
+        e("s_cbranch_scc1 L_nostamp0_%=")
+        e(f"s_cmp_lg_u32 {S_W}, 0")
+        e("s_cbranch_scc1 L_nostamp0_%=")
+        e("s_memtime s[98:99]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_mov_b32 v226, s98")
+        e("v_mov_b32 v227, s99")
+        e("s_memrealtime s[98:99]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_mov_b32 v228, s98")
+        e("v_mov_b32 v229, s99")
+        e("v_mov_b32 v224, s96")
+        e("v_mov_b32 v225, s97")
+        e("s_mov_b64 s[98:99], exec")
+        e("s_mov_b64 exec, 1")
+        e("global_store_dwordx4 v[224:225], v[226:229], off")
+        e("s_mov_b64 exec, s[98:99]")
+        e("L_nostamp0_%=:")
     e(f"s_lshr_b32 {S_RX8}, s58, 8")
     e(f"s_lshl_b32 {S_T}, {S_W}, 13")
     e(f"s_add_u32 {S_M0A}, {S_LDS0}, {S_T}")                      # this wave's 8 pieces of an A stage
@@ -232,22 +245,22 @@ def gen(NBT, sk=False):
         assert NBT == 16
         e("s_cmp_eq_u64 s[96:97], 0")
         e("s_cbranch_scc1 L_nostamp1_%=")
-        e("s_memtime s[76:77]")
-        e("s_memrealtime s[78:79]")
-        e("s_waitcnt lgkmcnt(0)")
         e(f"s_cmp_lg_u32 {S_W}, 0")
         e("s_cbranch_scc1 L_nostamp1_%=")
-        e("s_mov_b64 s[80:81], exec")
+        e("s_memtime s[98:99]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_mov_b32 v226, s98")
+        e("v_mov_b32 v227, s99")
+        e("s_memrealtime s[98:99]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_mov_b32 v228, s98")
+        e("v_mov_b32 v229, s99")
+        e("v_mov_b32 v224, s96")
+        e("v_mov_b32 v225, s97")
+        e("s_mov_b64 s[98:99], exec")
         e("s_mov_b64 exec, 1")
-        e("v_mov_b32 v226, s96")
-        e("v_mov_b32 v227, s97")
-        for k, r in enumerate((98, 99, 100, 101)):
-            e(f"v_mov_b32 v{228 + k}, s{r}")
-        e("global_store_dwordx4 v[226:227], v[228:231], off")
-        for k, r in enumerate((76, 77, 78, 79)):
-            e(f"v_mov_b32 v{232 + k}, s{r}")
-        e("global_store_dwordx4 v[226:227], v[232:235], off offset:16")
-        e("s_mov_b64 exec, s[80:81]")
+        e("global_store_dwordx4 v[224:225], v[226:229], off offset:16")
+        e("s_mov_b64 exec, s[98:99]")
         e("L_nostamp1_%=:")
         L.extend(gen_sk_tail())
 
@@ -255,7 +268,7 @@ def gen(NBT, sk=False):
     accs = ", ".join(f'"+{{a[{16 * j}:{16 * j + 15}]}}"(acc[{j}])' for j in range(NBT))
     clob = ['"memory"', '"scc"', '"vcc"']
     clob += [f'"v{n}"' for n in range(64, 248)]
-    clob += [f'"s{n}"' for n in range(42, 102 if sk else 96)]
+    clob += [f'"s{n}"' for n in range(42, 100 if sk else 96)]
     clob_s = ", ".join(clob)
     if sk:
         xp_enum = ", ".join(f"XP_{k} = {v}" for k, v in XP.items())
@@ -362,6 +375,7 @@ def gen_reduce(NP, C):
     e("s_mov_b32 s58, 0x04000C0C")
     e("s_mov_b32 s59, 0x0706000C")
     e("s_waitcnt vmcnt(0)")
+    L.extend(gen_stamp(4, f"r{NP}{C}"))                 # the partners' partials have arrived
     order = [("own", None) if pce == C else ("q", pce if pce < C else pce - 1) for pce in range(NP)]
 
     def unpack(base, jj, dst):
@@ -395,6 +409,30 @@ def gen_reduce(NP, C):
                             e(f"v_add_f32 v{216 + el}, v{216 + el}, v{src + el}")
                 for el in range(4):
                     e(f"v_accvgpr_write_b32 a{a0 + el}, v{216 + el}")
+    return L
+
+
+def gen_stamp(i, tag=""):
+    """diagnostic (tools/sk_clock.py): 100 MHz time into word 8 + i of the workgroup's stamp record, by lane 0 of wave 0, when the
+    record address s[96:97] is set (the shipping build passes 0: two scalar instructions and a branch). Clobbers SCC."""
+    L = []
+    e = L.append
+    lab = f"L_ns{i}{tag}_%="
+    e("s_cmp_eq_u64 s[96:97], 0")
+    e(f"s_cbranch_scc1 {lab}")
+    e("s_cmp_lg_u32 s62, 0")
+    e(f"s_cbranch_scc1 {lab}")
+    e("s_memrealtime s[98:99]")
+    e("s_waitcnt lgkmcnt(0)")
+    e("v_mov_b32 v236, s96")
+    e("v_mov_b32 v237, s97")
+    e("v_mov_b32 v238, s98")
+    e("v_mov_b32 v239, s99")
+    e("s_mov_b64 s[98:99], exec")
+    e("s_mov_b64 exec, 1")
+    e(f"global_store_dwordx2 v[236:237], v[238:239], off offset:{64 + 8 * i}")
+    e("s_mov_b64 exec, s[98:99]")
+    e(f"{lab}:")
     return L
 
 
@@ -441,8 +479,11 @@ def gen_sk_tail():
     e("L_pub2_%=:")
     L.extend(gen_publish(2))
     e("L_pubdone_%=:")
+    L.extend(gen_stamp(0))                              # publish issued
     e("s_waitcnt vmcnt(0)")                             # EVERY storing wave drains its write-through stores
+    L.extend(gen_stamp(1))                              # ... drained
     e("s_barrier")
+    L.extend(gen_stamp(2))
     # wave 0: raise this workgroup's flag (lane 0), then lanes 0 .. np-2 poll one partner's flag each (bounded)
     e("s_cmp_lg_u32 s62, 0")
     e("s_cbranch_scc1 L_flagdone_%=")
@@ -480,6 +521,7 @@ def gen_sk_tail():
     e("s_mov_b64 exec, s[64:65]")
     e("L_flagdone_%=:")
     e("s_barrier")
+    L.extend(gen_stamp(3))                              # every partner's flag seen
     # partner descriptors: base of partner q in xp lanes PSLAB + 2q, +1
     for q in range(3):
         for k in range(2):
@@ -506,6 +548,7 @@ def gen_sk_tail():
     e("L_red2n_%=:")
     L.extend(gen_reduce(2, 1))
     e("L_reddone_%=:")
+    L.extend(gen_stamp(5))                              # partials added
     e("s_nop 4")
     e("L_xdone_%=:")
     return L

@@ -71,6 +71,14 @@ def summarise(st, min_epoch, label=""):
         e["us"].append(float(us.median()))
         e.setdefault("clk_min", []).append(float(clk.min()))
         e.setdefault("clk_max", []).append(float(clk.max()))
+        if split > 1 and int(b[0, 14]) > 0:
+            # hand-off phases of gemm4w_sk_k (100 MHz stamps of wave 0, words 8-14): loop end -> publish issued -> stores drained ->
+            # barrier -> partners' flags seen -> partials arrived -> added -> tile stored
+            t = torch.stack([b[:, 3], b[:, 8], b[:, 9], b[:, 10], b[:, 11], b[:, 12], b[:, 13], b[:, 14]], 1).double()
+            good = (t[:, 1:] >= t[:, :-1]).all(1)
+            if bool(good.any()):
+                d = (t[good][:, 1:] - t[good][:, :-1]) / 100.0
+                e.setdefault("xchg", []).append([float(x) for x in d.median(0).values])
     epi_name = {0: "none", 1: "residual", 3: "swiglu_bwd", 4: "swiglu_fwd", 5: "swiglu_fwd_st", 6: "swiglu_bwd_st", 7: "rope"}
     print(f"# {label}: per shape — launches read, workgroups stamped, wide stages in the first segment, in-loop clock GHz "
           f"(median of per-launch medians; min / max over workgroups), loop us, TF/s inside the loop (all workgroups)")
@@ -85,10 +93,45 @@ def summarise(st, min_epoch, label=""):
         print(f"{M:5d} x {N:6d} x {K:6d} {epi_name.get(epi, epi):14s} split {split} tile 256x{16 * nbt:3d} out{ob}B  n={e['n']:3d} wgs={e['wgs']:3d} "
               f"nw={e['nw']:4d}  clock {clk:5.3f} GHz ({min(e['clk_min']):.3f} / {max(e['clk_max']):.3f})  loop {us:7.1f} us  "
               f"{fl / us / 1e6:7.0f} TF/s  -> MFMA pipe busy in-loop {fl / us / 1e6 / (256 * 4096 * clk * 1e-3) * (256 / e['wgs']):.3f} of the busy CUs' cycles")
+        if e.get("xchg"):
+            import numpy as np
+            m = np.median(np.array(e["xchg"]), 0)
+            print("        hand-off after the loop, us (median over workgroups and launches): publish issued %.2f | stores drained %.2f | barrier %.2f | "
+                  "flag + poll + barrier %.2f | partners' partials arrived %.2f | added %.2f | rows stored %.2f  (sum %.2f)" % (*m, m.sum()))
         tot_flop += fl * e["n"]
         tot_cyc += us * e["n"]
     if tot_cyc:
         print(f"# all stamped loops: {tot_flop / tot_cyc / 1e6:.0f} TF/s inside the loops")
+
+
+def per_xcd(st, min_epoch):
+    """Is the spread of the loop times over workgroups systematic? Per stamped launch of the long split-K shapes: median loop time and
+    clock of the 32 workgroups of each XCD chunk (work ids 32 x .. 32 x + 31 run on one XCD)."""
+    import torch
+    print("# per-XCD medians (loop us @ clock GHz) of the last launches of the K >= 11008 split shapes; rows = launches")
+    for r in range(RING):
+        blk = st[r]
+        used = blk[:, 1] > 0
+        if not bool(used.any()):
+            continue
+        ep = int(blk[used][:, 5].max())
+        if ep < min_epoch:
+            continue
+        meta = int(blk[used][0, 6])
+        split = (meta >> 8) & 0xFF
+        K = int(blk[used][0, 4]) & 0xFFFFFFFF
+        N = int(blk[used][0, 4]) >> 32
+        if split < 2 and os.environ.get("SK_CLOCK_XCD") != "all":
+            continue
+        if split >= 2 and K < 11008:
+            continue
+        ok = used & (blk[:, 5] == ep)
+        if int(ok.sum()) < 250:
+            continue
+        dr = (blk[:, 3] - blk[:, 1]).double() / 100.0
+        clk = (blk[:, 2] - blk[:, 0]).double() / (blk[:, 3] - blk[:, 1]).double().clamp(min=1) * 0.1
+        cells = [f"{float(dr[32 * x:32 * x + 32].median()):6.1f}@{float(clk[32 * x:32 * x + 32].median()):.2f}" for x in range(8)]
+        print(f"  N={N:6d} K={K:6d} split {split} epoch {ep:8d}: " + " ".join(cells) + f"   spread {float(dr.max() - dr.min()):5.1f} us")
 
 
 def mode_step(seconds):
@@ -142,6 +185,8 @@ def mode_step(seconds):
     st = read_ring(ws, need)
     last = int(st[:, :, 5].max())
     summarise(st, last - 257, "C2 step, last 258 launches (gemm4w_sk_k or gemm_sk_256: split 2/4; gemm4w_k: split 1, first tile of a workgroup)")
+    if os.environ.get("SK_CLOCK_XCD"):
+        per_xcd(st, last - 257)
 
 
 def mode_b2b(seconds):

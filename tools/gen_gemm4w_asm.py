@@ -23,6 +23,11 @@ Register map (per wave):
   v[64:79]  set 0 activation fragments   v[80:80+4*NBT-1]   set 0 weight fragments
   v[144:159] set 1 activation fragments  v[160:160+4*NBT-1] set 1 weight fragments
   v[224:229] read addresses              v[232:239] / v[240:247] per-piece DMA offsets (A / B)      s[44:95] scalars
+
+The split-K form (`Ring4AsmSK`, NBT = 16 only; gemm_sk.hip gemm4w_sk_k) appends the whole hand-off between the pieces of a tile to
+the SAME statement ("split-K exchange" section below): its parameters arrive in one VGPR operand, parameter k in lane k
+(v_readlane), the partners' flag addresses in a second one; s[96:99] and the registers the loop no longer needs carry the
+diagnostic stamps (record address 0 in the shipping build = two scalar instructions and a branch per stamp).
 """
 import os
 import sys

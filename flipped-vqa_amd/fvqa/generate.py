@@ -89,7 +89,7 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
             pred = lg.argmax(-1)
         if persistent and int(ws[16:24].view(torch.int64)[0].item()) != 0:
             raise RuntimeError("fvqa_decode_token: a grid barrier timed out (the device was not this process's alone?); "
-                               "FVQA_DECODE_PERSISTENT=0 selects the per-kernel token loop")
+                               "unset FVQA_DECODE_PERSISTENT for the per-kernel token loop (the default)")
         return ids
     finally:
         eng._gen_arena = eng._arena

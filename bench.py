@@ -17,12 +17,18 @@ Prints ONE JSON line (rank 0) with the contract fields plus
                  HIP events the library records on the launch stream around every 17th launch in an
                  INSTRUMENTED repeat of the same steps under the same native schedule (that pass's own
                  ms_per_step is in the line; a pass with every launch bracketed is reported as
-                 `dense_probe`); `alg_bytes_per_launch` (operands + outputs of each launch, from its shape)
+                 `dense_probe`). Round 5: the bracketed durations are used AS MEASURED (rounds 3-4 subtracted an
+                 "empty event pair" of ~4.9 us from every launch; the durations of `rocprofv3 --kernel-trace --stats`
+                 tile the step and agree with the un-subtracted figure, so the subtraction flattered `frac` by 2-5 %); `alg_bytes_per_launch` (operands + outputs of each launch, from its shape)
                  stands beside `traffic` (fabric bytes per launch from the committed PMC passes);
   step_roofline— algorithmic FLOPs of the whole step (SURVEY §8d formula) / step time;
   cpu_baseline — the CPU oracle (oracle/ref_cpu.py) timed on this host's cores on BASELINE configs[0]:
-                 full-depth 7B, B=2, all three losses, forward+backward+AdamW, one warm-up + up to three timed
-                 steps within a host-time budget (rank 0, N=1 only).
+                 full-depth 7B, B=2, all three losses, forward+backward+AdamW, one warm-up + timed steps within a
+                 host-time budget (rank 0, N=1 only; ONE timed step while the other-config legs are on);
+  other_configs— (N=1, default workload only) short legs — 3 warm-up + 10 timed steps each, same step, same GPU, after the
+                 C2 legs have freed their model — of BASELINE configs[2..4] as ONE GPU runs them: c3 = 7B three losses,
+                 c4 = 7B seq_len 650 batch 1 three losses, c5 = 13B batch 4 three losses: {ms_per_step, samples_per_s,
+                 step_roofline} each (what profiles/r0N_bench_c{3,4,5}.json used to hold builder-run only).
 """
 import argparse
 import json
@@ -109,7 +115,7 @@ def _cpu_extrapolated(seq_len, max_feats):
                       f"({times[1]:.2f}s, {times[2]:.2f}s) and scaled to 32 layers + head ({full:.1f}s/step)"}
 
 
-def cpu_baseline_leg(seq_len, max_feats, budget_s=240.0):
+def cpu_baseline_leg(seq_len, max_feats, budget_s=240.0, max_timed=3):
     """The CPU oracle (oracle/ref_cpu.py, fp32) timed on this host's cores on SURVEY §8d's sample: BASELINE configs[0] (C1)
     — the full 32-layer 7B, B = 2 samples of the same sequence length, ALL THREE flipped losses (--vaq --qav) — forward +
     backward + AdamW(0.9, 0.95) on the 4.5 M trainables, one warm-up step (first touch of 27 GB of weights) and up to three
@@ -141,7 +147,7 @@ def cpu_baseline_leg(seq_len, max_feats, budget_s=240.0):
 
         t_start = time.perf_counter()
         times = []
-        for i in range(4):                         # warm-up + up to three timed steps
+        for i in range(1 + max_timed):             # warm-up + up to max_timed timed steps
             t0 = time.perf_counter()
             one_step()
             times.append(time.perf_counter() - t0)
@@ -229,6 +235,84 @@ def self_launch(n_gpus, argv):
             signal.signal(sg, h)
 
 
+OTHER_CONFIGS = {   # BASELINE configs[2..4] as ONE GPU runs them (reference README.md:62-96 recipes)
+    "c3": dict(model="7B", batch_size=8, seq_len=128, vaq=True, qav=True),
+    "c4": dict(model="7B", batch_size=1, seq_len=650, vaq=True, qav=True),
+    "c5": dict(model="13B", batch_size=4, seq_len=128, vaq=True, qav=True),
+}
+
+
+def short_leg(dev, model_name, batch_size, seq_len, vaq, qav, dtype="bf16", steps=10, warmup=3):
+    """One more BASELINE shape on the same GPU: builds its model, runs `warmup` + `steps` full training steps (forward, the
+    flipped losses, backward, unscale + norm, AdamW) on cycling resident batches, returns its line fragment. Frees everything
+    it built."""
+    import contextlib
+    import gc
+    import util.misc as misc
+    from fvqa import synth
+    from fvqa.optim import FusedAdamW, param_groups_weight_decay
+    from llama_vqa import LLaMA_VQA
+    args = types.SimpleNamespace(
+        llama_model_path="/nonexistent/", model=model_name, max_seq_len=seq_len, adapter_len=10,
+        adapter_layer=40 if model_name == "13B" else 32, max_feats=10, bias=3.5, tau=100.0, vaq=vaq, qav=qav,
+        audio=False, audio_only=False, audio_merge="none", debug=False, synthetic=True, random_init=True,
+        dtype=dtype, accum_iter=1, weight_decay=0.14)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = LLaMA_VQA(args)
+    model.to(dev)
+    p = model.params
+    opt = FusedAdamW(param_groups_weight_decay(model, args.weight_decay), lr=9e-2 * batch_size / 256, betas=(0.9, 0.95),
+                     flat=model.flat_params())
+    scaler = misc.NativeScalerWithGradNormCount()
+    cfg = synth.SynthConfig(dim=p.dim, n_heads=p.n_heads, n_layers=p.n_layers, vocab_size=model.vocab_size,
+                            max_seq_len=seq_len, batch_size=batch_size, vaq=vaq, qav=qav)
+    batches = []
+    for i in range(4):
+        b = synth.make_batch(cfg, seed=1234 + i)
+        b["video"] = b["video"].to(dev)
+        for k in ("text_id", "label", "video_index"):
+            b[k] = {t: v.to(dev) for t, v in b[k].items()}
+        batches.append(b)
+
+    def one_step(i):
+        opt.zero_grad()
+        vqa_l, vaq_l, qav_l = model(batches[i % 4])
+        loss = vqa_l + vaq_l + qav_l
+        scaler(loss, opt, parameters=None, update_grad=True)
+        return loss
+
+    for i in range(warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    err = None
+    try:
+        model.ensure_engine().check_gemm_error()
+    except RuntimeError as e:
+        err = str(e)
+    tasks = ["vqa"] + (["vaq"] if vaq else []) + (["qav"] if qav else [])
+    L = len(model.engine_layer_ids())
+    Hf = model.layers[0].feed_forward.w1.weight.shape[0]
+    fl = step_flops(p.dim, p.n_heads, L, Hf, model.vocab_size, batch_size, seq_len, 10, 10, tasks)
+    ms = dt / steps * 1e3
+    out = {"workload": f"LLaMA-{model_name} {dtype} seq_len={seq_len} batch={batch_size}/GPU max_feats=10 "
+                       f"losses={'+'.join(tasks)} fwd+bwd+AdamW, {L} layers",
+           "steps": steps, "warmup": warmup, "ms_per_step": ms, "samples_per_s": batch_size * steps / dt,
+           "loss": float(loss.detach().sum()),
+           "step_roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
+                             "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / MFMA_BF16_PEAK, "flops_per_step": fl}}
+    if err is not None:
+        out["invalid"] = err
+    del model, opt, scaler, batches
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,6 +326,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--n_layers", type=int, default=0, help="debug only: reduced depth (marks the line invalid)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_other_configs", action="store_true",
+                    help="skip the short C3 / C4 / C5 legs that follow the default (C2) workload at N = 1")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -379,6 +465,9 @@ def main():
         rank_ms = [float(x[0].item()) / a.steps * 1e3 for x in per_rank]
         comm = {"allreduce_ms": float(t[1].item()), "allreduce_calls_per_step": len(comm_ms) / a.steps,
                 "ms_per_step_per_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+                # each rank's own rate = what an N = 1 run of the same per-GPU work reads as `value` (compare with BENCH directly)
+                "samples_per_s_per_rank": {"min": a.batch_size / max(rank_ms) * 1e3, "max": a.batch_size / min(rank_ms) * 1e3,
+                                           "all": [a.batch_size / m * 1e3 for m in rank_ms]},
                 "allreduce_ms_per_rank": [float(x[1].item()) for x in per_rank],
                 "allreduce_bytes": int(model.flat_params().flat_grad.numel() * 4),
                 "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
@@ -419,8 +508,8 @@ def main():
     ms_sparse, rec_sparse = instrumented(STRIDE)
     ms_dense, rec_dense = instrumented(1)
     if rank == 0 and rec_sparse:
-        # calibration: what an event pair with NOTHING between reads on this stream (the record-to-record spacing that
-        # every bracketed launch also contains); subtracted per launch so that the figure is the kernel's own duration
+        # what an event pair with NOTHING between reads on this stream: reported (`empty_event_pair_us`), NOT subtracted —
+        # the un-subtracted brackets are what agrees with the rocprofv3 kernel durations of the same command
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(129)]
         for ev in evs:
             ev.record()
@@ -444,7 +533,7 @@ def main():
                 e[0] += 1
                 if us >= 0:
                     e[1] += 1
-                    e[2] += max(us - probe_overhead_us, 0.0)
+                    e[2] += us                      # as measured: no "empty event pair" subtracted (see the docstring)
             per, tot_ms, tot_f, n_launch, n_timed, missing = {}, 0.0, 0.0, 0, 0, 0
             for (kind, fl), (cnt, nt, sum_us) in sh.items():
                 if nt == 0:
@@ -474,8 +563,8 @@ def main():
             stride_used, ms_pass = 1, ms_dense
         if gemm_ms > 0:
             peak = MFMA_BF16_PEAK if a.dtype == "bf16" else 157.3e12
-            events_ms = n_timed / a.steps * probe_overhead_us * 1e-3
-            non_gemm_ms = ms_pass - gemm_ms - events_ms        # everything of a step that is not this kernel
+            events_ms = n_timed / a.steps * probe_overhead_us * 1e-3   # (reported only: the brackets contain it)
+            non_gemm_ms = ms_pass - gemm_ms                    # everything of a step that is not this kernel
             achieved = flops_step / (gemm_ms * 1e-3)
             # fabric-side bytes per launch from the rocprofv3 --pmc passes of THIS command (tools/pmc_summary.py:
             # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), valid only for the kernel sources they were collected with
@@ -503,7 +592,7 @@ def main():
                     "avg_flops_per_launch": flops_step / (n_launch / a.steps),
                     "ms_per_step_this_pass": ms_pass, "ms_per_step_timed_region": ms,
                     "non_gemm_ms_per_step": non_gemm_ms, "event_pairs_ms_per_step": events_ms,
-                    "probe_overhead_us_subtracted": probe_overhead_us,
+                    "probe_overhead_us_subtracted": 0.0, "empty_event_pair_us": probe_overhead_us,
                     "dense_probe": {"frac": (flops_dense / (gemm_ms_dense * 1e-3) / peak) if gemm_ms_dense > 0 else None,
                                     "gemm_ms_per_step": gemm_ms_dense, "ms_per_step_this_pass": ms_dense,
                                     "note": "every launch bracketed (rounds 1-2 method): lighter duty cycle, reads high"},
@@ -555,9 +644,32 @@ def main():
         if os.environ.get("FVQA_BENCH_REHEARSAL") == "1":
             out["rehearsal"] = True
             out["invalid"] = "rehearsal: ranks share devices over gloo (not a scaling measurement)"
+        if world > 1:
+            out["value_per_gpu"] = value / world         # the N = 1-equivalent rate: read it against BENCH's `value`
+        default_workload = (a.model == "7B" and a.batch_size == 8 and a.seq_len == 128 and a.dtype == "bf16"
+                            and not (a.vaq or a.qav) and not a.n_layers)
+        legs_on = world == 1 and default_workload and not a.no_other_configs
+        if legs_on:
+            # BASELINE configs[2..4] as one GPU runs them, driver-timed with the C2 line (round-4 verdict #3): free the C2
+            # model first (7B: ~30 GiB with the transposed copies; the 13B leg needs ~58)
+            import gc
+            opt.grad_sync = None
+            del net, opt, scaler, batches, model
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = {}
+            for name, c in OTHER_CONFIGS.items():
+                t_leg = time.time()
+                try:
+                    out["other_configs"][name] = short_leg(dev, c["model"], c["batch_size"], c["seq_len"], c["vaq"], c["qav"])
+                    out["other_configs"][name]["leg_wall_s"] = time.time() - t_leg
+                except Exception as e:   # a leg must never take the headline measurement down
+                    out["other_configs"][name] = {"error": repr(e)[:300]}
+                print(f"[bench] {name}: {out['other_configs'][name]}", file=sys.stderr, flush=True)
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline_leg(a.seq_len, 10)
+                # with the legs on, ONE timed oracle step (warm-up + one: ~170 s on the box's 128 threads) keeps the command < 450 s
+                out["cpu_baseline"] = cpu_baseline_leg(a.seq_len, 10, max_timed=1 if legs_on else 3)
             except Exception as e:   # the baseline leg must never take the GPU measurement down
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -96,5 +96,17 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// hipFuncSetAttribute applies to the CURRENT device: a once-per-process flag would leave every other device of a process that
+// drives several (tests, tools; one process per GPU never does) without its dynamic-LDS limit. One bit per device id.
+#include <atomic>
+static inline bool fvqa_attr_needed(std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const unsigned long long bit = 1ull << dev;
+  if (done.load(std::memory_order_relaxed) & bit) return false;
+  done.fetch_or(bit);
+  return true;
+}
+
 static inline int fvqa_dtype_ok(int dt) { return dt == FVQA_F32 || dt == FVQA_BF16; }
 static inline size_t fvqa_dtype_size(int dt) { return dt == FVQA_F32 ? 4 : 2; }

@@ -27,10 +27,9 @@ using namespace fvqa_g4;
 template <int NBT, typename TO, int EPI>
 int launch4(const G4Args& a, hipStream_t st) {
   auto k = gemm4w_k<NBT, TO, EPI>;
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load()) {
+  static std::atomic<unsigned long long> attr_done{0};          // one bit per device (fvqa_attr_needed)
+  if (fvqa_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<NBT>::RING_BYTES);
-    attr_done.store(true);
   }
   {
     FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (sizeof(TO) == 4 ? 32 : 0) | 128);       // kind bit 7: the 4-wave kernel
@@ -93,6 +92,15 @@ static double g4_cost_us(int M, int N, int K, int nbt, int epilogue, int out_dty
   return total;
 }
 
+// Test / tuning override of the tile width (include/fvqa.h fvqa_gemm4w_force): per host thread, 0 = the cost model.
+static thread_local int g_force_nbt = 0;
+extern "C" int fvqa_gemm4w_force(int nbt) {
+  if (nbt != 0 && nbt != 11 && nbt != 12 && nbt != 13 && nbt != 14 && nbt != 16) return FVQA_EINVAL;
+  const int prev = g_force_nbt;
+  g_force_nbt = nbt;
+  return prev;
+}
+
 // Tile width (in 16-column blocks) the 4-wave kernel would use, 0 when the problem is not its to take.
 extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider,
                                   int n_cu) {
@@ -105,10 +113,11 @@ extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype,
     return 0;
   if (M < 192 || N < 256 || (K % 64) || (N & 7) || n_cu < 8 || n_cu > 256) return 0;
   static const char* force = getenv("FVQA_GEMM4W_NBT");
+  const int forced = g_force_nbt ? g_force_nbt : (force && force[0] ? atoi(force) : 0);
   int best = 0;
   double best_c = 1e30;
   for (int nbt : {16, 14, 13, 12, 11}) {
-    if (force && force[0] && atoi(force) != nbt) continue;
+    if (forced && forced != nbt) continue;
     if (epilogue == FVQA_EPI_SWIGLU_FWD_ST && (nbt & 1)) continue;     // (a, b) pairs of 16-column blocks must not straddle tiles
     const double c = g4_cost_us(M, N, K, nbt, epilogue, out_dtype, rider, n_cu, nullptr);
     if (c < best_c) { best_c = c; best = nbt; }

@@ -9,9 +9,11 @@
 // bf16 = two k-steps of v_mfma_f32_16x16x32_bf16 in NT form with the WEIGHT fragment as the row operand: a lane holds 4
 // consecutive output columns of one row).
 //   * LDS-DMA rings: activations A 2 x 32 KiB, weights B 3 x (2*NBT) KiB; every piece is 8 rows x 128 B = whole cache
-//     lines, moved by `buffer_load_dwordx4 ... offen lds` with ONE per-lane offset register per operand (the piece's row
-//     block and the stage's K offset ride in the SCALAR offset, so a DMA costs the wave no vector-ALU work) and hardware
-//     bounds checking: rows past M / N read as zeros, no clamped pointers;
+//     lines, moved by `buffer_load_dwordx4 ... offen lds` with ONE per-lane offset register PER PIECE (row block of the piece
+//     + swizzled chunk, computed once before the loop: tools/gen_gemm4w_asm.py VA / VB) and only the stage's K offset in the
+//     SCALAR offset, so a DMA costs the wave no vector-ALU work inside the loop. The hardware range check covers the per-lane
+//     offset only — which is why the ROW part of every address must stay there: rows past M / N then read as zeros, no
+//     clamped pointers (moving the row block into the scalar offset would silently drop the zero-fill of edge tiles);
 //   * a wave moves exactly the 64 activation rows it reads itself, plus its quarter of the weight rows;
 //   * the image is lane-linear (DMA constraint), XOR-swizzled on the SOURCE offset and on the ds_read_b128 address
 //     (chunk c of row r sits at chunk c ^ (r & 7): conflict-free fragment reads, as in gemm256_loop.h);

@@ -646,10 +646,9 @@ __global__ __launch_bounds__(256) void gemm4w_sk_k(const SkArgs a) {
 template <typename TO, int EPI>
 int launch_sk4(const SkArgs& a, hipStream_t st) {
   auto k = gemm4w_sk_k<TO, EPI>;
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load()) {
+  static std::atomic<unsigned long long> attr_done{0};          // one bit per device (fvqa_attr_needed)
+  if (fvqa_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, fvqa_ring4::Geo<16>::RING_BYTES);
-    attr_done.store(true);
   }
   {
     FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (a.plan.s > 1 ? 16 : 0) | (sizeof(TO) == 4 ? 32 : 0) | 128);
@@ -664,10 +663,9 @@ std::atomic<unsigned long long> g_epoch{0};
 template <typename T, typename TO, int EPI>
 int launch_sk(const SkArgs& a, hipStream_t st) {
   auto k = gemm_sk_256<T, TO, EPI>;
-  static std::atomic<bool> attr_done{false};
-  if (!attr_done.load()) {
+  static std::atomic<unsigned long long> attr_done{0};          // one bit per device (fvqa_attr_needed)
+  if (fvqa_attr_needed(attr_done)) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, RING_BYTES);
-    attr_done.store(true);
   }
   {
     FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (a.plan.s > 1 ? 16 : 0) | (sizeof(TO) == 4 ? 32 : 0) | (sizeof(T) == 4 ? 64 : 0));
@@ -762,7 +760,10 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     // for 256 CUs) stays here.
     const int cus = n_cu < 256 ? n_cu : 256;
     const fvqa_sk_plan p0 = fvqa_sk_make_plan(M, N, K, 64, cus);
-    if (!(p0.full == 0 && p0.s > 1)) {
+    // (the 4-wave loop addresses its operands with 32-bit DMA offsets: operands of 2 GiB or more — ~97k rows at K = 11008 —
+    // stay with the 8-wave kernel below instead of failing; round-4 advisor finding)
+    const bool dma32 = (size_t)M * lda * 2 < 0x7fffffffull && (size_t)N * ldb * 2 < 0x7fffffffull;
+    if (dma32 && !(p0.full == 0 && p0.s > 1)) {
       const int nbt = fvqa_gemm4w_choose(M, N, K, dtype, out_dtype, epilogue, rider, cus);
       if (nbt) {
         unsigned long long* cst = nullptr;

@@ -78,9 +78,16 @@ def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: to
         if getattr(args, "debug", False):
             break
 
+    # The LAST iteration's error state. found_inf = 2 is the all-reduced error lane (fvqa/parallel.py: every rank sees it when
+    # ANY rank's split-K exchange timed out), so every rank stops here together; reading only the local error word would raise
+    # on the faulty rank alone and leave the healthy ones waiting in the meter all-reduce below (round-4 advisor finding).
+    found_dev = getattr(loss_scaler, "_found", None)
+    if torch.is_tensor(found_dev) and float(found_dev.reshape(-1)[0].item()) == 2.0:
+        raise RuntimeError("fvqa: a split-K exchange of the persistent GEMM timed out on some rank (found_inf = 2): the last "
+                           "optimizer step was skipped on every rank and the results of its launches are invalid")
     eng = getattr(getattr(model, "module", model), "_engine", None)
     if eng is not None:
-        eng.check_gemm_error()                                # the last iteration's (include/fvqa.h: error word)
+        eng.check_gemm_error()                                # this rank's own word (include/fvqa.h: error word)
     log.synchronize_between_processes()
     print("Averaged stats:", log)
     return {k: m.global_avg for k, m in log.meters.items()}

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST = 0, 1, 3, 6
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -31,6 +31,8 @@ SIGNATURES = {
     "fvqa_swiglu_st": (_i, []),
     "fvqa_gemm_nt_rider": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "fvqa_gemm_sk_describe": (_i, [_i, _i, _i, _i, _i, _p, _i, _p, _i]),
+    "fvqa_gemm4w_choose": (_i, [_i, _i, _i, _i, _i, _i, _p, _i]),
+    "fvqa_gemm4w_force": (_i, [_i]),
     "fvqa_gemm_timing_enable": (_i, [_i]),
     "fvqa_gemm_timing_read": (_i, [_i, _p, _p, _p]),
     "fvqa_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
@@ -43,10 +45,6 @@ SIGNATURES = {
     "fvqa_gemm_nt_rope": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "fvqa_attn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_attn_decode": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "fvqa_decode_workspace": (_sz, []),
-    "fvqa_decode_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "fvqa_decode_token_ok": (_i, [_i, _i, _i, _i, _i, _i, _i]),
-    "fvqa_decode_token": (_i, [_p, _i, _p, _p, _p, _sz, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _i, _p]),
     "fvqa_attn_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "fvqa_attn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),
     "fvqa_attn_bwd_rotated": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _p]),

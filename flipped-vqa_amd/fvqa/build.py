@@ -51,6 +51,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _content_key(src: str, headers, flags) -> str:
+    """What an object was compiled from: sha256 of its source, every header it may include and the flags. Objects are chosen
+    for recompilation by CONTENT, not by mtime (round-4 advisor finding: rsync -t, tar, git checkout of older files or clock
+    skew between the build box and the GPU box leave a changed source older than its object — the library would then carry
+    the new source hash over old kernels and the load-time stale-binary guard would accept it)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for f in [src] + sorted(headers):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 LAST_BUILD = {"compiled": 0, "linked": False}        # what the last build() call did (tests, __graft_entry__.build)
 
 
@@ -65,7 +78,7 @@ def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=())
     shash = source_hash()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "fvqa.h"))
-    jobs, objs = [], []
+    jobs, objs, keys = [], [], {}
     for src in sources():
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
@@ -74,8 +87,13 @@ def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=())
             if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != shash:
                 jobs.append([hipcc, *FLAGS, f'-DFVQA_SOURCE_HASH="{shash}"', "-c", src, "-o", obj])
             continue
-        if force or _stale(obj, [src] + headers):
+        key = _content_key(src, headers, FLAGS)
+        keyf = obj + ".key"
+        if force or not os.path.exists(obj) or not os.path.exists(keyf) or open(keyf).read() != key:
+            if os.path.exists(keyf):
+                os.remove(keyf)                                   # (a failed compile must not leave a matching key behind)
             jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            keys[obj] = key
 
     def run(cmd):
         if verbose:
@@ -89,6 +107,8 @@ def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=())
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     open(os.path.join(OBJDIR, "version.o.hash"), "w").write(shash)
+    for obj, key in keys.items():
+        open(obj + ".key", "w").write(key)
     link = bool(jobs) or force or _stale(LIB, objs)
     if link:
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])

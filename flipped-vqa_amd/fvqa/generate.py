@@ -50,26 +50,13 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
         xn, hn, h, x2, o_row = e(B, D), e(B, D), e(B, D), e(B, D), e(B, D)
         qkv_row, ab, z = e(B, 3 * D), e(B, 2 * Hf), e(B, Hf)
         lg = e(B, V, dtype=torch.float32)
-        # opt-in (FVQA_DECODE_PERSISTENT=1): one persistent launch per token for all layers (csrc/decode.hip: the same arithmetic,
-        # grid barriers instead of launch boundaries; measured slower than the per-kernel sequence below, which is the default)
-        persistent = ops.decode_persistent_enabled() and ops.decode_token_ok(B, S, H, Dh, Hf, A, eng.dtype)
-        if persistent:
-            rows = [[pk.an[i], pk.wqkv[i], pk.wo[i], pk.fn[i], pk.w13[i], pk.w2[i], ar.qkv[i], *m.gate_views(i)] for i in range(L)]
-            persistent = all(t.is_contiguous() for r in rows for t in r)
-        if persistent:
-            table = torch.tensor([[t.data_ptr() for t in r] for r in rows], dtype=torch.int64, device=dev)
-            scratch = ops.decode_scratch(L, B, H, Dh, Hf, dev)
-            ws = ops.decode_workspace(dev)
         for _ in range(n_new):
             ok = pos + 1 < S                                # the reference would index past the end here
             tgt = (pos + 1).clamp(max=S - 1)
             ids[torch.arange(B, device=dev), tgt] = torch.where(ok, pred, ids[torch.arange(B, device=dev), tgt])
             pos = tgt
             x = pk.emb[ids[torch.arange(B, device=dev), pos]].contiguous()
-            if persistent:
-                x = ops.decode_token(table, L, x, x2, scratch, vstart, pos, (eng.cos, eng.sin), B, S, H, Dh, Hf, A, F,
-                                     eng.eps, not fused, ws)
-            for i in range(0 if persistent else L):           # the per-kernel sequence of a layer
+            for i in range(L):                                # the per-kernel sequence of a layer
                 ops.rmsnorm_fwd(x, pk.an[i], xn, None, eng.eps, rows=B)
                 ops.gemm_nt(xn, pk.wqkv[i], qkv_row)
                 g1, g2 = m.gate_views(i)
@@ -87,9 +74,6 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
             ops.rmsnorm_fwd(x, pk.norm, xn, None, eng.eps, rows=B)
             ops.gemm_nt(xn, pk.wout, lg)
             pred = lg.argmax(-1)
-        if persistent and int(ws[16:24].view(torch.int64)[0].item()) != 0:
-            raise RuntimeError("fvqa_decode_token: a grid barrier timed out (the device was not this process's alone?); "
-                               "unset FVQA_DECODE_PERSISTENT for the per-kernel token loop (the default)")
         return ids
     finally:
         eng._gen_arena = eng._arena

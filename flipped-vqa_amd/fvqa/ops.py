@@ -105,9 +105,43 @@ def gemm_error(ws: Optional[torch.Tensor] = None, device=None) -> int:
     return bad
 
 
+class gemm4w_width:
+    """`with ops.gemm4w_width(nbt):` — the whole-tile bf16 projections launched by THIS host thread inside the block use tiles of
+    16 * nbt columns (nbt in 11, 12, 13, 14, 16) instead of the cost model's pick (include/fvqa.h fvqa_gemm4w_force); tests and
+    the width sweep of tools/gemm4w_widths.py. nbt = 0 / None: the cost model."""
+
+    def __init__(self, nbt: Optional[int]):
+        self.nbt = int(nbt or 0)
+
+    def __enter__(self):
+        self.prev = int(_lib.load().fvqa_gemm4w_force(self.nbt))
+        _need(self.prev >= 0, f"gemm4w_width: no tile width of {self.nbt} x 16 columns")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().fvqa_gemm4w_force(self.prev)
+        return False
+
+
+def gemm4w_choose(M: int, N: int, K: int, *, out_f32: bool = False, epilogue: int = EPI_NONE, rider_nk=None,
+                  n_cu: int = 256) -> int:
+    """Tile width (in 16-column blocks) the cost model picks for a bf16 projection on n_cu CUs; 0 = not the whole-tile kernel's
+    problem. rider_nk: (N2, K2) of a <= 16-row rider product carried by the launch. Host only (no GPU touched)."""
+    import ctypes as C
+    rd = None
+    if rider_nk is not None:
+        rd = _lib.SkRider(1, 1, 1, 10, int(rider_nk[0]), int(rider_nk[1]), int(rider_nk[1]), int(rider_nk[1]), int(rider_nk[0]), 0)
+    return int(_lib.load().fvqa_gemm4w_choose(M, N, K, _lib.BF16, _lib.F32 if out_f32 else _lib.BF16, epilogue,
+                                              C.addressof(rd) if rd is not None else None, n_cu))
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Optional[torch.Tensor] = None,
-            tail: Optional[torch.Tensor] = None, m_split: int = 0, variant: int = 0) -> torch.Tensor:
-    """out[M,N] = a[M,K] @ b[N,K]^T (+ residual). Rows >= m_split go to `tail` (fp32) when given."""
+            tail: Optional[torch.Tensor] = None, m_split: int = 0, variant: int = 0, nbt: Optional[int] = None) -> torch.Tensor:
+    """out[M,N] = a[M,K] @ b[N,K]^T (+ residual). Rows >= m_split go to `tail` (fp32) when given. nbt: force the whole-tile
+    kernel's tile width for this call (gemm4w_width)."""
+    if nbt:
+        with gemm4w_width(nbt):
+            return gemm_nt(a, b, out, residual=residual, tail=tail, m_split=m_split, variant=variant)
     _dev(a, b, out, residual, rows_strided=True)
     _dev(tail)
     _need(a.dim() == 2 and b.dim() == 2, "gemm_nt: 2-D operands")
@@ -471,53 +505,6 @@ def attn_decode(qkv_row, qkv_cache, o_row, gate1, gate2, vstart, pos, rope, n_se
 
 
 DECODE_PTRS = 9
-
-
-def decode_token_ok(n_seq, S, H, Dh, Hf, A, dtype) -> bool:
-    """True when fvqa_decode_token (one persistent launch per generated token) serves this shape."""
-    return bool(_lib.load().fvqa_decode_token_ok(n_seq, S, H, Dh, Hf, A, dt_code(dtype)))
-
-
-def decode_persistent_enabled() -> bool:
-    """The persistent per-token launch is exact but measured slower than the per-kernel token loop (csrc/decode.hip): opt-in."""
-    import os
-    return os.environ.get("FVQA_DECODE_PERSISTENT", "0") == "1"
-
-
-def decode_scratch(n_layers, n_seq, H, Dh, Hf, device) -> torch.Tensor:
-    """Scratch of fvqa_decode_token: one set of row buffers per layer + every workgroup's private normalised rows."""
-    n = int(_lib.load().fvqa_decode_scratch_bytes(n_layers, n_seq, H, Dh, Hf))
-    return torch.empty(n + 256, dtype=torch.uint8, device=device)
-
-
-def decode_workspace(device) -> torch.Tensor:
-    return torch.zeros(int(_lib.load().fvqa_decode_workspace()), dtype=torch.uint8, device=device)
-
-
-def decode_token(table, n_layers, x, x_out, scratch, vstart, pos, rope, n_seq, S, H, Dh, Hf, A, F, eps, cache_rotated: bool, ws):
-    """All layers of one generated token in one launch (csrc/decode.hip). table: int64 device tensor (n_layers, DECODE_PTRS)
-    of addresses; x (n_seq, D): the new rows, x_out (n_seq, D): the last layer's output rows. The error word of `ws` (byte 16)
-    is nonzero after the launch if a grid barrier timed out — generate.greedy_decode reads it back with the ids."""
-    _dev(table, x, x_out, scratch, vstart, pos, ws)
-    D = H * Dh
-    cos_t, sin_t = _rope_tables(rope, S, Dh, "decode_token")
-    _need(cos_t is not None, "decode_token: rope tables")
-    _need(table.dtype == torch.int64 and tuple(table.shape) == (n_layers, DECODE_PTRS) and table.is_contiguous(),
-          "decode_token: table")
-    for t in (x, x_out):
-        _need(t.dtype == torch.bfloat16 and tuple(t.shape) == (n_seq, D) and t.is_contiguous(), "decode_token: x / x_out")
-    _need(x.data_ptr() != x_out.data_ptr(), "decode_token: x_out must not be x")
-    _need(scratch.dtype == torch.uint8, "decode_token: scratch")
-    off = (-scratch.data_ptr()) % 256                      # the library wants 256-byte alignment
-    nbytes = scratch.numel() - off
-    _need(pos.dtype == torch.int64 and pos.numel() == n_seq, "decode_token: pos")
-    _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "decode_token: vstart")
-    _need(ws.numel() * ws.element_size() >= int(_lib.load().fvqa_decode_workspace()), "decode_token: workspace")
-    rc = _lib.load().fvqa_decode_token(_ptr(table), n_layers, _ptr(x), _ptr(x_out), scratch.data_ptr() + off, nbytes,
-                                       _ptr(vstart), _ptr(pos), _ptr(cos_t), _ptr(sin_t), n_seq, S, H, Dh, Hf, A, F,
-                                       float(eps), 1 if cache_rotated else 0, _ptr(ws), dt_code(x.dtype), _stream())
-    _lib.check(rc, "fvqa_decode_token")
-    return x_out
 
 
 def attn_bwd_workspace(n_seq, S, H, Dh, A) -> int:

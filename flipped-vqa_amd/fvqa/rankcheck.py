@@ -24,7 +24,7 @@ def local_report(rank: int, local_rank: int, device_index: int) -> Dict:
     import torch
     rep = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "device_index": device_index,
            "device_count": torch.cuda.device_count(), "omp_num_threads": os.environ.get("OMP_NUM_THREADS"),
-           "cpu_count": os.cpu_count()}
+           "torch_threads": torch.get_num_threads(), "cpu_count": os.cpu_count()}
     if torch.cuda.is_available() and device_index < torch.cuda.device_count():
         p = torch.cuda.get_device_properties(device_index)
         ident = None
@@ -73,9 +73,19 @@ def verify(reports: List[Dict], asked_world: int, group_world: int, rehearsal: b
         arch = r.get("gcn_arch")
         if arch is not None and "gfx950" not in str(arch):
             bad.append(f"rank {r['rank']}: device architecture {arch}, the kernels are built for gfx950")
-        if len(reports) > 1 and not r.get("omp_num_threads"):
-            bad.append(f"rank {r['rank']}: OMP_NUM_THREADS is not set ({len(reports)} ranks would each start one host "
-                       f"thread per core of {r.get('cpu_count')})")
+        # host threads: what counts is the EFFECTIVE intra-op thread count of the rank (pin_host_threads caps it and exports
+        # OMP_NUM_THREADS; launchers that set neither — mpirun --dist_on_itp, srun: reference util/misc.py:221-236 — are fine
+        # once the rank has pinned itself). A rank whose threads are still one per core of the host is the problem.
+        n_on_host = sum(1 for q in reports if q.get("host") == r.get("host"))
+        thr, cpus = r.get("torch_threads"), r.get("cpu_count")
+        if n_on_host > 1:
+            if thr is None:
+                if not r.get("omp_num_threads"):
+                    bad.append(f"rank {r['rank']}: OMP_NUM_THREADS is not set ({n_on_host} ranks on {r.get('host')} would each "
+                               f"start one host thread per core of {cpus})")
+            elif cpus and thr * n_on_host > cpus and thr > 1:
+                bad.append(f"warning: rank {r['rank']}: {thr} torch host threads x {n_on_host} ranks on {r.get('host')} oversubscribe its "
+                           f"{cpus} cores (call rankcheck.pin_host_threads(world) or set OMP_NUM_THREADS per rank)")
     return bad
 
 
@@ -92,19 +102,27 @@ def check_ranks(asked_world: int, rank: int, local_rank: int, device_index: int,
     else:
         world, gathered = 1, [mine]
     problems = verify(gathered, asked_world, world, rehearsal=rehearsal)
-    if problems and strict:
+    fatal = [p for p in problems if not p.startswith("warning:")]       # (oversubscribed host threads slow a run, they do not break it)
+    if fatal and strict:
         raise RuntimeError("fvqa: the data-parallel configuration is not sound:\n  " + "\n  ".join(problems))
+    if rank == 0:
+        for p in problems:
+            if p.startswith("warning:"):
+                print(f"[fvqa.rankcheck] {p}", flush=True)
     return {"reports": gathered, "problems": problems}
 
 
 def pin_host_threads(world: int, workers_per_rank: int = 0) -> int:
     """torch host threads of this rank: its share of the host's cores minus the loader workers it will start (at least 1).
-    Honours an OMP_NUM_THREADS the launcher set (bench.launcher_env / torchrun set one per rank)."""
+    Honours an OMP_NUM_THREADS the launcher set (bench.launcher_env / torchrun set one per rank); otherwise — mpirun with
+    --dist_on_itp, SLURM srun: the launchers reference util/misc.py:221-236 also accepts set none — it EXPORTS the value it
+    chose, so that child processes (loader workers) and the start-up check see the same number."""
     import torch
     env = os.environ.get("OMP_NUM_THREADS")
     if env:
         n = max(1, int(env))
     else:
         n = max(1, (os.cpu_count() or 1) // max(1, world) - workers_per_rank)
+        os.environ["OMP_NUM_THREADS"] = str(n)
     torch.set_num_threads(n)
     return n

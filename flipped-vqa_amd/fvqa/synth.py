@@ -82,6 +82,11 @@ class SynthConfig:
     # so each position's logits peak at the token (or frame token) that position holds, with a top-2 margin of about
     # half the logit range instead of the few per cent that 32000 independent random rows leave
     peaked: bool = False
+    # round 5 (generation fixtures): as `peaked`, but the LM head is tied to the embedding rows through a fixed PERMUTATION pi of
+    # the vocabulary — output row pi(t) = embedding row t — so a position holding token t predicts pi(t) != t: a greedy decode
+    # walks t -> pi(t) -> pi(pi(t)) ... (31 distinct ids per row, margins as decided as with the identity tie) instead of
+    # repeating the token it was fed, and a wrong KV-cache row / position in the token loop changes the next id.
+    peaked_perm: bool = False
 
     @property
     def head_dim(self) -> int:
@@ -124,7 +129,7 @@ def state_spec(cfg: SynthConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
     yield "tok_embeddings.weight", (V, D), "emb"
     yield "adapter_query.weight", (cfg.adapter_len * cfg.adapter_layer, D), "emb"
     yield "visual_proj.weight", (D, cfg.video_dim), "lin"
-    yield "temporal_emb.weight", (cfg.max_feats, D), "tied_temporal" if cfg.peaked else "emb"
+    yield "temporal_emb.weight", (cfg.max_feats, D), "tied_temporal" if (cfg.peaked or cfg.peaked_perm) else "emb"
     for i in range(cfg.n_layers):
         p = f"layers.{i}."
         yield p + "attention.wq.weight", (D, D), "lin"
@@ -139,7 +144,7 @@ def state_spec(cfg: SynthConfig) -> Iterator[Tuple[str, Tuple[int, ...], str]]:
         yield p + "attention_norm.weight", (D,), "norm"
         yield p + "ffn_norm.weight", (D,), "norm"
     yield "norm.weight", (D,), "norm"
-    yield "output.weight", (V, D), "tied_out" if cfg.peaked else "lin"
+    yield "output.weight", (V, D), "tied_out_perm" if cfg.peaked_perm else ("tied_out" if cfg.peaked else "lin")
 
 
 TRAINABLE_MARKS = ("gate", "adapter", "temporal_emb", "visual_proj")   # reference llama_vqa.py:72
@@ -156,10 +161,14 @@ def make_tensor(cfg: SynthConfig, name: str, shape, kind: str, device="cpu") -> 
         return hashed_uniform(name, shape, math.sqrt(3.0), device)
     if kind == "norm":
         return hashed_uniform(name, shape, 0.1, device, offset=1.0)
-    if kind in ("tied_out", "tied_temporal"):           # SynthConfig.peaked
+    if kind in ("tied_out", "tied_out_perm", "tied_temporal"):           # SynthConfig.peaked / peaked_perm
         emb = hashed_uniform("tok_embeddings.weight", (cfg.vocab_size, cfg.dim), math.sqrt(3.0), device)
         if kind == "tied_out":
             return emb * (1.0 / math.sqrt(cfg.dim))
+        if kind == "tied_out_perm":
+            out = torch.empty_like(emb)
+            out[vocab_permutation(cfg.vocab_size, device)] = emb * (1.0 / math.sqrt(cfg.dim))      # row pi(t) <- embedding row t
+            return out
         tok = [(97 + 31 * f) % cfg.vocab_size for f in range(shape[0])]
         return 3.0 * emb[torch.tensor(tok, dtype=torch.int64, device=device)]
     if kind == "gate1":
@@ -171,6 +180,14 @@ def make_tensor(cfg: SynthConfig, name: str, shape, kind: str, device="cpu") -> 
             else torch.full(shape, -cfg.bias, dtype=torch.float32, device=device)
         return g
     raise KeyError(kind)
+
+
+def vocab_permutation(V: int, device="cpu") -> torch.Tensor:
+    """pi(t) = (a t + c) mod V with gcd(a, V) = 1 (a bijection of the vocabulary without short cycles for the sizes used:
+    V = 32000 = 2^8 5^3 and V = 512 / 1024 are all coprime with 7919)."""
+    a, c = 7919, 12345
+    assert math.gcd(a, V) == 1
+    return (torch.arange(V, dtype=torch.int64, device=device) * a + c) % V
 
 
 def state_dict(cfg: SynthConfig, device="cpu") -> Dict[str, torch.Tensor]:

@@ -150,6 +150,15 @@ int fvqa_gemm_nt_rope(const void* A, const void* B, void* C, int M, int N, int K
                       void* stream);
 int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
                           int32_t* segs_out, int max_segs);
+/* The whole-tile bf16 projections (outputs wide enough to fill the chip: q|k|v, w1|w3, dH·W2^T, LM head) run on tiles of
+ * 256 rows x 16*nbt columns, nbt in {16, 14, 13, 12, 11} chosen per problem by a cost model so that the tile count lands on the
+ * CU count. fvqa_gemm4w_choose (host only): the nbt the model picks for a problem on n_cu compute units, 0 when the problem is
+ * not that kernel's (fp32 build, K % 64, M < 192, N < 256, an epilogue it does not have). `rider` may be NULL.
+ * fvqa_gemm4w_force: tests / tuning — every following projection call OF THE CALLING HOST THREAD uses tiles of 16*nbt columns
+ * where the kernel is eligible at all (odd nbt never with FVQA_EPI_SWIGLU_FWD_ST: (a, b) column blocks pair up); 0 restores the
+ * cost model. Returns the previous setting, FVQA_EINVAL for a width that does not exist. */
+int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype, int epilogue, const fvqa_sk_rider* rider, int n_cu);
+int fvqa_gemm4w_force(int nbt);
 /* Measurement probe (bench.py roofline; no reference counterpart): while enabled, launches of the persistent
  * 256x256 GEMM kernel are bracketed by HIP events on THEIR launch stream. enable(n): n = 1 brackets every launch, n > 1
  * every n-th launch (the others are only counted) — an event pair idles the chip for ~5 us, and a stream with one after
@@ -220,31 +229,6 @@ int fvqa_attn_decode(const void* qkv_row, void* qkv_cache, void* o_row, const fl
                      const int32_t* vstart, const int64_t* pos, const float* cos_t, const float* sin_t, int n_seq,
                      int seq_len, int n_heads, int head_dim, int adapter_len, int max_feats, int cache_rotated,
                      int dtype, void* stream);
-/* One generated token through ALL layers as one persistent launch (bf16 build; the per-token loop of the reference's
- * generation, llama/model.py:428-470, restricted to the new rows): per layer RMSNorm -> QKV rows -> fvqa_attn_decode's attention
- * -> WO + residual -> RMSNorm -> W1|W3 rows -> SwiGLU -> W2 + residual, phases separated by grid barriers. Bit for bit the
- * arithmetic of the per-kernel sequence fvqa_rmsnorm_fwd / fvqa_gemm_nt (M <= 16) / fvqa_attn_decode / fvqa_swiglu_fwd.
- *   table: DEVICE array, n_layers x FVQA_DECODE_PTRS addresses per layer: attention-norm weight, Wqkv (3*dim, dim), Wo, ffn-norm
- *          weight, W1|W3 (2*hidden, dim; AB16 row order), W2 (dim, hidden), the layer's qkv cache (see fvqa_attn_decode),
- *          gate1, gate2 (fp32 per head)
- *   x (n_seq, dim): the new tokens' rows (read only); x_out (n_seq, dim): the last layer's output rows
- *   scratch: fvqa_decode_scratch_bytes(...) bytes, 256-byte aligned — one set of row buffers PER LAYER (rows handed from phase
- *   to phase are written write-through and never rewritten inside a launch, so no cache is flushed or invalidated between
- *   phases) and every workgroup's private normalised rows; ws: fvqa_decode_workspace() bytes (barrier counter; error word at
- *   byte 16: nonzero after the launch = a grid barrier timed out, the rows are not valid; bytes 64.. diagnostic stamps);
- *   pos / vstart / tables / cache_rotated as fvqa_attn_decode.
- * The launch fills the device with resident workgroups (it wants the device to itself, like the persistent projection kernel).
- * fvqa_decode_token_ok: 1 when the shape is served (bf16, n_seq <= 16, head_dim 128, dim a multiple of 256 up to 6144, hidden a
- * multiple of 256). MEASURED SLOWER than the per-kernel sequence on the MI355X (200 against 138 us per 7B layer, csrc/decode.hip):
- * the generation path uses it only with FVQA_DECODE_PERSISTENT=1. */
-#define FVQA_DECODE_PTRS 9
-size_t fvqa_decode_workspace(void);
-size_t fvqa_decode_scratch_bytes(int n_layers, int n_seq, int n_heads, int head_dim, int hidden);
-int fvqa_decode_token_ok(int n_seq, int seq_len, int n_heads, int head_dim, int hidden, int adapter_len, int dtype);
-int fvqa_decode_token(const uint64_t* table, int n_layers, const void* x, void* x_out, void* scratch, size_t scratch_bytes,
-                      const int32_t* vstart, const int64_t* pos, const float* cos_t, const float* sin_t, int n_seq,
-                      int seq_len, int n_heads, int head_dim, int hidden, int adapter_len, int max_feats, float eps,
-                      int cache_rotated, void* ws, int dtype, void* stream);
 /* workspace bytes fvqa_attn_bwd needs (fp32 partials for the batch-summed adapter k/v
  * gradients and the per-head gate sums). Its FIRST 1024 BYTES are integer arrival counters of the
  * fused bf16 backward: the caller zeroes them once after allocating the workspace; every call

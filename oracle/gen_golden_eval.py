@@ -59,8 +59,13 @@ def main():
     # the reference model (tiny width — or, with argument "7b_l2", 7B width two layers deep —, full vocabulary so that the
     # prompt ids are valid)
     pname = sys.argv[1] if len(sys.argv) > 1 else "tiny"
-    peaked = len(sys.argv) > 2 and sys.argv[2] == "peaked"
-    cfg = synth.preset(pname, vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4, peaked=peaked)
+    mode = sys.argv[2] if len(sys.argv) > 2 else ""
+    assert mode in ("", "peaked", "peakedperm"), mode
+    peaked = mode == "peaked"
+    # "peakedperm" (round 5): LM head tied to a PERMUTATION of the embedding rows (SynthConfig.peaked_perm) — the greedy trajectory
+    # moves, token t is followed by pi(t), so the ids pin the KV cache / position handling of a token loop, not only its head
+    cfg = synth.preset(pname, vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4, peaked=peaked,
+                       peaked_perm=mode == "peakedperm")
     model, margs = G.build_reference(M, cfg)
     margs.is_generation_task = True
     model.eval()
@@ -108,10 +113,11 @@ def main():
            "vstart_vqa": np.array(batch["video_start"]["vqa"], dtype=np.int64),
            "answer": batch["answer"].numpy(), "video": batch["video"].numpy(),
            "qtype": batch["qtype"].numpy(), "min_margin_per_call": np.array(margins, dtype=np.float32)}
-    path = os.path.join(ROOT, "tests", "golden", f"eval_{pname}{'_peaked' if peaked else ''}.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"eval_{pname}{'_' + mode if mode else ''}.npz")
     np.savez_compressed(path, **out)
     print("best", out["best"], "answers", out["answer"], "->", path, os.path.getsize(path) // 1024, "KiB")
     print("generated (first sample):", out["ids_after"][0, out["prefix_vqa"][0] - 2: out["prefix_vqa"][0] + 8])
+    print("distinct ids per row:", [len(set(r.tolist())) for r in out["ids_after"]], "min margin", float(np.min(margins)))
 
 
 if __name__ == "__main__":

@@ -37,6 +37,9 @@ CASES = {
     "7b_full_s650_vqa_peaked": ("7b", dict(batch_size=1, max_seq_len=650, vaq=False, qav=False, peaked=True)),
     "7b_l2_s650_all_peaked": ("7b_l2", dict(batch_size=1, max_seq_len=650, vaq=True, qav=True, peaked=True)),
     "13b_l2_all_peaked": ("13b", dict(n_layers=2, adapter_layer=2, batch_size=4, vaq=True, qav=True, peaked=True)),
+    # round 5: C3 (B=8, three streams) and C5 (13B) SIXTEEN layers deep — the depth whose fp32 reference fits the build container
+    "7b_l16_b8_all_peaked": ("7b", dict(n_layers=16, adapter_layer=16, batch_size=8, vaq=True, qav=True, peaked=True)),
+    "13b_l16_all_peaked": ("13b", dict(n_layers=16, adapter_layer=16, batch_size=4, vaq=True, qav=True, peaked=True)),
     # the other shapes the reference's training commands use (README.md:79,87: DramaQA S=384 B=2, VLEP S=256 B=4), 7B width
     "7b_l2_s256_b4_all_peaked": ("7b_l2", dict(batch_size=4, max_seq_len=256, vaq=True, qav=True, peaked=True)),
     "7b_l2_s384_b2_all_peaked": ("7b_l2", dict(batch_size=2, max_seq_len=384, vaq=True, qav=True, peaked=True)),

@@ -13,7 +13,7 @@ import engine
 from util import misc
 
 GOLDS = {p: dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"eval_{p}.npz")))
-         for p in ("tiny", "7b_l2", "tiny_peaked", "7b_l2_peaked")}
+         for p in ("tiny", "7b_l2", "tiny_peaked", "7b_l2_peaked", "tiny_peakedperm", "7b_l2_peakedperm")}
 GOLD = GOLDS["tiny"]
 
 
@@ -27,7 +27,7 @@ def golden_batch(GOLD=GOLD):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pname", ["tiny", "7b_l2", "tiny_peaked", "7b_l2_peaked"])
+@pytest.mark.parametrize("pname", ["tiny", "7b_l2", "tiny_peaked", "7b_l2_peaked", "tiny_peakedperm", "7b_l2_peakedperm"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_generation_matches_reference(dtype, pname):
     """fp32 build: the 31 greedy tokens per sample, the chosen option and the similarities equal the reference's
@@ -36,13 +36,26 @@ def test_generation_matches_reference(dtype, pname):
     tied to the token embeddings, so the reference's top-2 margin is 0.55 / 0.86 of the logit range at every one of the 31 x 4
     greedy steps, recorded in the fixture): token ids equal, similarities within 2e-2, chosen option equal wherever the
     reference's own top-2 similarities are more than 4e-2 apart. On the random-LM-head fixtures a bf16 build is only checked for
-    determinism (their margins are below its error band)."""
+    determinism (their margins are below its error band).
+    Round 5, `*_peakedperm` (SynthConfig.peaked_perm: LM head tied to a PERMUTATION pi of the embedding rows): with the identity
+    tie every greedy step returned the token it was fed (~30 of the 31 ids of a row were one id), so a wrong KV-cache row,
+    position or cache_rotated handling that left the argmax at the input token passed. Here token t is followed by pi(t): the
+    31 generated ids of a row are all different, each the image of the previous one, at margins of 0.55 / 0.86 of the range."""
     from fvqa import synth
     from tests.gpu_util import build_model
     GOLD = GOLDS[pname]
-    peaked = pname.endswith("_peaked")
-    cfg = synth.preset(pname[:-len("_peaked")] if peaked else pname, vaq=False, qav=False, vocab_size=32000, max_seq_len=128,
-                       batch_size=4, peaked=peaked)
+    perm = pname.endswith("_peakedperm")
+    peaked = pname.endswith("_peaked") or perm
+    base = pname[:pname.rindex("_peaked")] if peaked else pname
+    cfg = synth.preset(base, vaq=False, qav=False, vocab_size=32000, max_seq_len=128, batch_size=4, peaked=peaked and not perm,
+                       peaked_perm=perm)
+    if perm:                                    # what the fixture must be for the pin to mean anything (reference-generated)
+        pi = synth.vocab_permutation(32000).numpy()
+        for b in range(GOLD["ids_after"].shape[0]):
+            p0 = int(GOLD["prefix_vqa"][b])
+            gen = GOLD["ids_after"][b, p0:p0 + 31]
+            assert len(set(gen.tolist())) == len(gen) >= 20                          # a trajectory that moves ...
+            assert np.array_equal(gen[1:], pi[gen[:-1]])                             # ... along the permutation
     model, _ = build_model(cfg, dtype)
     model.eval()
     batch = golden_batch(GOLD)
@@ -79,7 +92,8 @@ def test_generation_matches_reference(dtype, pname):
 def test_bf16_generation_is_pinned_in_both_rope_modes(rope_in_gemm):
     """The KV cache of the generation path holds ROTATED keys when the QKV projection rotates in its epilogue (the default,
     FVQA_ROPE_IN_GEMM=1) and RAW keys otherwise; fvqa_attn_decode is told which (cache_rotated = !attn_rope_fused ||
-    rope_in_gemm). Either way the bf16 build reproduces the reference's tokens on the peaked fixtures. The switch is read once
+    rope_in_gemm). Either way the bf16 build reproduces the reference's tokens on the peaked fixtures — including the permuted ones,
+    whose 31 ids per row all differ (a cached key rotated twice, or not at all, moves the trajectory). The switch is read once
     per process, so each mode runs in a child process."""
     import subprocess
     import sys
@@ -87,29 +101,13 @@ def test_bf16_generation_is_pinned_in_both_rope_modes(rope_in_gemm):
     code = ("import torch, tests.test_eval as T\n"
             "from fvqa import ops\n"
             f"assert ops.rope_in_gemm(torch.bfloat16) == {rope_in_gemm == '1'}\n"
-            "for p in ('tiny_peaked', '7b_l2_peaked'):\n"
+            "for p in ('tiny_peaked', '7b_l2_peaked', 'tiny_peakedperm', '7b_l2_peakedperm'):\n"
             "    T.test_generation_matches_reference(torch.bfloat16, p)\n"
             "print('ok')\n")
     env = dict(os.environ, FVQA_ROPE_IN_GEMM=rope_in_gemm, FVQA_SYNTHETIC_TOKENIZER="1",
                PYTHONPATH=os.pathsep.join([root, os.path.join(root, "flipped-vqa_amd"), os.environ.get("PYTHONPATH", "")]))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
-
-
-@pytest.mark.gpu
-def test_bf16_generation_with_the_persistent_token_kernel(monkeypatch):
-    """FVQA_DECODE_PERSISTENT=1: every generated token runs all layers in ONE persistent launch (csrc/decode.hip; opt-in, measured
-    slower than the per-kernel token loop). Same arithmetic, so the bf16 build still reproduces the reference's 31 x 4 tokens,
-    similarities and decided options on the peaked 7B-width fixture."""
-    from fvqa import ops
-    assert ops.decode_token_ok(4, 128, 32, 128, 11008, 10, torch.bfloat16)
-    monkeypatch.setenv("FVQA_DECODE_PERSISTENT", "1")
-    assert ops.decode_persistent_enabled()
-    calls = []
-    real = ops.decode_token
-    monkeypatch.setattr(ops, "decode_token", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
-    test_generation_matches_reference(torch.bfloat16, "7b_l2_peaked")
-    assert len(calls) == 31                                   # one launch per generated token
 
 
 @pytest.mark.gpu

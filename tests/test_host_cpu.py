@@ -341,3 +341,58 @@ def test_rank_startup_checks_name_what_is_wrong():
     wrong_arch = [dict(rep(0, 0), gcn_arch="gfx942")]
     assert any("gfx950" in p for p in rankcheck.verify(wrong_arch, 1, 1))
     assert rankcheck.verify([rep(0, 0, omp=None)], 1, 1) == []                    # a single rank need not pin its threads
+    # the effective thread count is what is judged once a rank reports it: a rank that pinned itself without the variable
+    # (mpirun --dist_on_itp, srun) is sound, one still at a thread per core is warned about — and a warning never raises
+    pinned = [dict(rep(r, r, omp=None), torch_threads=16) for r in range(8)]
+    assert rankcheck.verify(pinned, 8, 8) == []
+    greedy = [dict(rep(r, r, omp=None), torch_threads=128) for r in range(8)]
+    assert all(p.startswith("warning:") and "oversubscribe" in p for p in rankcheck.verify(greedy, 8, 8))
+
+
+def test_init_distributed_mode_without_omp_num_threads(monkeypatch):
+    """Round-4 advisor finding: launchers the reference's init_distributed_mode accepts (util/misc.py:221-236: mpirun with
+    --dist_on_itp, SLURM srun) set no OMP_NUM_THREADS; pin_host_threads then chooses the rank's share, EXPORTS it, and the
+    start-up check (which used to read only the environment and abort every rank) passes."""
+    import torch
+    from fvqa import rankcheck
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    before = torch.get_num_threads()
+    try:
+        n = rankcheck.pin_host_threads(8, workers_per_rank=2)
+        assert n == max(1, (os.cpu_count() or 1) // 8 - 2)
+        assert os.environ["OMP_NUM_THREADS"] == str(n) and torch.get_num_threads() == n
+        mine = rankcheck.local_report(0, 0, 0)
+        assert mine["omp_num_threads"] == str(n) and mine["torch_threads"] == n
+        peers = [dict(mine, rank=r, local_rank=r, device_index=r, device_id=f"uuid:{r}", cu_count=256, device_count=8,
+                      gcn_arch="gfx950") for r in range(8)]
+        assert rankcheck.verify(peers, 8, 8) == []
+    finally:
+        torch.set_num_threads(before)
+
+
+def test_train_one_epoch_stops_every_rank_on_an_error_lane_set_in_the_last_iteration():
+    """Round-4 advisor finding: found_inf = 2 (the all-reduced error lane: SOME rank's split-K exchange timed out) left by the
+    LAST iteration of an epoch used to be read by nobody — the faulty rank raised on its own error word, the healthy ones walked
+    into the meter all-reduce and waited for it forever. engine.train_one_epoch (reference engine.py:10-56) now reads the loss
+    scaler's found-inf word after the loop on EVERY rank. Host logic only: stub model and scaler, no device."""
+    import types
+    import engine
+
+    class Scaler:
+        def __init__(self, fault_at):
+            self._found, self.calls, self.fault_at = torch.zeros(1), 0, fault_at
+
+        def __call__(self, loss, optimizer, parameters=None, update_grad=True):
+            self.calls += 1
+            self._found = torch.tensor([2.0 if self.calls == self.fault_at else 0.0])
+
+    class Model(torch.nn.Module):               # a HEALTHY rank: no engine error word of its own
+        def forward(self, data):
+            return torch.tensor(1.0), torch.tensor(0.5), torch.tensor(0.25)
+
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.1}], zero_grad=lambda: None)
+    args = types.SimpleNamespace(accum_iter=1, lr=0.1, min_lr=0.0, warmup_epochs=1, epochs=2, debug=False)
+    stats = engine.train_one_epoch(Model(), [0, 1, 2, 3], opt, 0, Scaler(fault_at=0), args=args)
+    assert abs(stats["loss"] - 1.75) < 1e-6
+    with pytest.raises(RuntimeError, match="found_inf = 2"):
+        engine.train_one_epoch(Model(), [0, 1, 2, 3], opt, 0, Scaler(fault_at=4), args=args)

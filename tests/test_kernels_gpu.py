@@ -244,6 +244,120 @@ def test_gemm_nt_rope_epilogue(n_seq, S, H, K):
     assert rel(out[:M, :D], qr.reshape(M, D)) < 1e-2
 
 
+def _kinds_of(fn):
+    """kinds (include/fvqa.h fvqa_gemm_timing_read) of the projection launches fn() makes: bit 7 = the 4-wave kernels, bit 4 = split-K"""
+    ops.gemm_timing_enable(True, 1)
+    try:
+        fn()
+        return [k for (_, _, k) in ops.gemm_timing_read()]
+    finally:
+        ops.gemm_timing_enable(False)
+
+
+G4_WIDTHS = [11, 12, 13, 14, 16]
+
+
+@pytest.mark.parametrize("nbt", G4_WIDTHS)
+@pytest.mark.parametrize("epi", ["none", "f32out", "residual", "rope", "swiglu_fwd_st", "swiglu_bwd_st"])
+def test_gemm4w_every_width(nbt, epi):
+    """Every tile width of the whole-tile bf16 kernel (gemm4w_k: 256 rows x 16*nbt columns, one generated main loop per width)
+    x every epilogue it carries, FORCED through ops.gemm4w_width (an argument of the call path, not a once-read environment
+    variable) on shapes ragged in M and N — edge tiles rely on the DMA's hardware range check zero-filling rows past M / N —
+    against fp64; the launch record must show that the 4-wave kernel, not a fallback, produced the result. Until round 5 the
+    widths were only covered through whatever the cost model picked for the step's shapes (F.linear of llama/model.py:89, :142,
+    :348 and the dX of w2)."""
+    dt = torch.bfloat16
+    if epi == "swiglu_fwd_st" and nbt % 2:
+        # (a, b) column blocks pair up inside a tile: an odd width is never used with this epilogue, forced or not
+        assert ops.gemm4w_choose(1024, 22016, 4096, epilogue=5) % 2 == 0
+        with ops.gemm4w_width(nbt):
+            assert ops.gemm4w_choose(1024, 22016, 4096, epilogue=5) == 0
+        return
+    K = 320
+    if epi in ("none", "f32out", "residual"):
+        M, N = 1034, 3000                                              # 5 x ceil(3000 / 16 nbt) tiles, ragged both ways
+        a, b = rnd(M, K, dtype=dt, seed=1), rnd(N, K, dtype=dt, scale=1 / math.sqrt(K), seed=2)
+        r = rnd(M, N, dtype=dt, seed=3) if epi == "residual" else None
+        out = torch.full((M, N), float("nan"), dtype=torch.float32 if epi == "f32out" else dt, device=DEV)
+        kinds = _kinds_of(lambda: ops.gemm_nt(dev(a), dev(b), out, residual=dev(r) if r is not None else None, nbt=nbt))
+        ref = a.double() @ b.double().T + (r.double() if r is not None else 0)
+        assert rel(out, ref) < (2e-5 if epi == "f32out" else 1e-2)
+    elif epi == "rope":
+        n_seq, S, H, Dh = 3, 200, 4, 128                               # M = 600 (ragged), N = 1536, rope on the q | k columns
+        D, M = H * Dh, n_seq * S
+        x, w = rnd(M, K, dtype=dt, seed=81), rnd(3 * D, K, dtype=dt, scale=1 / math.sqrt(K), seed=82)
+        cos, sin = ref_cpu.rope_tables(2 * S, Dh, torch.float32)
+        out = torch.full((M, 3 * D), float("nan"), dtype=dt, device=DEV)
+        with ops.gemm4w_width(nbt):
+            kinds = _kinds_of(lambda: ops.gemm_nt_rope(dev(x), dev(w), out, (dev(cos), dev(sin)), S, Dh, H))
+        raw = (x.double() @ w.double().T).to(dt).double()              # the epilogue rotates the bf16-rounded product
+        qk = ref_cpu.rope_apply(raw[:, :2 * D].reshape(n_seq, S, 2 * H, Dh), cos[:S].double(), sin[:S].double()).reshape(M, 2 * D)
+        assert rel(out[:, :2 * D], qk) < 1e-2 and rel(out[:, 2 * D:], raw[:, 2 * D:]) < 1e-2
+    else:
+        M, Hf, D = 1034, 1520, K                                        # N = 3040 AB16 columns (fwd) / 1520 (bwd), ragged
+        x = rnd(M, D, dtype=dt, seed=45)
+        w1, w3 = rnd(Hf, D, dtype=dt, scale=2 / math.sqrt(D), seed=46), rnd(Hf, D, dtype=dt, scale=2 / math.sqrt(D), seed=47)
+        w13 = ops.pack_ab16(w1.T.contiguous(), w3.T.contiguous()).T.contiguous()
+        a_, b_ = x.double() @ w1.double().T, x.double() @ w3.double().T
+        sg = torch.sigmoid(a_)
+        s_ref, t_ref = a_ * sg, b_ * sg * (1 + a_ * (1 - sg))
+        st = torch.full((M, 2 * Hf), float("nan"), dtype=dt, device=DEV)
+        z = torch.full((M, Hf), float("nan"), dtype=dt, device=DEV)
+        if epi == "swiglu_fwd_st":
+            with ops.gemm4w_width(nbt):
+                kinds = _kinds_of(lambda: ops.gemm_nt_swiglu_fwd(dev(x), dev(w13), st, z, st=True))
+            gs, gt = ops.unpack_ab16(st)
+            assert rel(gs, s_ref) < 1e-2 and rel(gt, t_ref) < 1e-2 and rel(z, s_ref * b_) < 2e-2
+        else:
+            st.copy_(ops.pack_ab16(s_ref.to(dt), t_ref.to(dt)))
+            g, w2t = rnd(M, 448, dtype=dt, seed=41), rnd(Hf, 448, dtype=dt, scale=1 / math.sqrt(448), seed=42)
+            dab = torch.full((M, 2 * Hf), float("nan"), dtype=dt, device=DEV)
+            with ops.gemm4w_width(nbt):
+                kinds = _kinds_of(lambda: ops.gemm_nt_swiglu_bwd(dev(g), dev(w2t), st, dab, st=True))
+            dz = g.double() @ w2t.double().T
+            ga, gb = ops.unpack_ab16(dab)
+            assert rel(ga, dz * t_ref.to(dt).double()) < 1e-2 and rel(gb, dz * s_ref.to(dt).double()) < 1e-2
+    assert len(kinds) == 1 and kinds[0] & 128 and not kinds[0] & 16, kinds       # gemm4w_k itself, whole tiles
+    assert ops.gemm_error() == 0
+
+
+@pytest.mark.parametrize("M,N,K,resid", [(1000, 4000, 4096, False), (1000, 4000, 4096, True), (520, 4088, 2048, True),
+                                         (1024, 4096, 11008, True)])
+def test_gemm4w_split_k_on_ragged_tiles(M, N, K, resid):
+    """The split-K form of the 4-wave loop (gemm4w_sk_k: 256 x 256 tiles cut 2 or 4 ways along K, hand-off inside the loop's own
+    statement) on tile sets ragged in M and N (round-4 advisor: its edge tiles were only covered because generic shapes
+    happened to route there): fp64 parity, every output word written, and the launch record names the kernel (reference
+    F.linear of llama/model.py:127-128 wo, :142 w2 and the dX products)."""
+    dt = torch.bfloat16
+    a, b = rnd(M, K, dtype=dt, seed=5), rnd(N, K, dtype=dt, scale=1 / math.sqrt(K), seed=6)
+    r = rnd(M, N, dtype=dt, seed=7) if resid else None
+    out = torch.full((M, N), float("nan"), dtype=dt, device=DEV)
+    kinds = _kinds_of(lambda: ops.gemm_nt(dev(a), dev(b), out, residual=dev(r) if resid else None))
+    assert len(kinds) == 1 and kinds[0] & 128 and kinds[0] & 16, kinds               # gemm4w_sk_k
+    ref = a.double() @ b.double().T + (r.double() if resid else 0)
+    assert rel(out, ref) < 1e-2
+    assert ops.gemm_error() == 0
+
+
+def test_operands_of_2gib_stay_off_the_32_bit_dma_kernel():
+    """Round-4 advisor finding: the 4-wave loop addresses operands with 32-bit DMA offsets; a bf16 operand of 2 GiB or more
+    (~97.6k rows at K = 11008) used to come back FVQA_ESHAPE instead of falling through to the 8-wave kernel. Host-side
+    decision only (no 2 GiB allocation here): the chooser still names a width for the shape — the size guard sits in front of
+    it in fvqa_gemm_sk_impl — and a launch just under the limit runs and matches."""
+    assert ops.gemm4w_choose(98304, 4096, 11008) > 0
+    M, K, N = 2304, 64, 512                               # lda padded so that M * lda * 2 crosses 2 GiB: 2304 * 466048 * 2
+    lda = 466048
+    big = torch.zeros(M * lda, dtype=torch.bfloat16, device=DEV)
+    a = big.view(M, lda)[:, :K]
+    a.copy_(dev(rnd(M, K, dtype=torch.bfloat16, seed=9)))
+    b = dev(rnd(N, K, dtype=torch.bfloat16, scale=1 / 8, seed=10))
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    kinds = _kinds_of(lambda: ops.gemm_nt(a, b, out))
+    assert len(kinds) == 1 and not kinds[0] & 128, kinds  # the 8-wave kernel took it
+    assert rel(out, a.double().cpu() @ b.double().cpu().T) < 1e-2
+    del big
+
+
 @pytest.mark.parametrize("M,N,K", [(8, 4096, 4096), (1, 520, 256), (16, 1000, 2816), (3, 22016, 1024)])
 def test_gemm_nt_skinny_decode_shape(M, N, K):
     """M <= 16 (one new token per sequence, generation path): the weight-streaming kernel, forced (variant 12)
@@ -855,77 +969,3 @@ def test_set_error_word_skips_the_optimizer_step_and_raises():
         word.view(torch.int64)[0] = 0
     step()
     assert scaler._found.item() == 0.0 and not torch.equal(flat.flat, p1)
-
-
-# ------------------------------------------------------------------------------ one generated token, all layers in one launch
-def _ab16_rows(w1, w3):
-    """W1 | W3 in the engine's AB16 row order: blocks of 16 W1 rows and 16 W3 rows alternate (fvqa/step.py pack)."""
-    Hf, D = w1.shape
-    return torch.stack([w1.view(Hf // 16, 16, D), w3.view(Hf // 16, 16, D)], dim=1).reshape(2 * Hf, D).contiguous()
-
-
-@pytest.mark.parametrize("B,S,H,Hf,L,pos", [(3, 64, 4, 768, 2, [63, 5, 30]), (8, 128, 2, 1280, 3, [127, 0, 64, 9, 100, 33, 2, 77]),
-                                            (16, 40, 2, 512, 1, list(range(20, 36)))])
-def test_decode_token_equals_the_per_kernel_sequence(B, S, H, Hf, L, pos):
-    """fvqa_decode_token (csrc/decode.hip: every layer of one generated token in ONE persistent launch, grid barriers between
-    the phases) against the sequence of stand-alone kernels fvqa/generate.py issues otherwise — rmsnorm_fwd, gemm_nt (M <= 16),
-    attn_decode, swiglu_fwd: the rows after the last layer and every layer's cache (the new tokens' k, v included)
-    must be BITWISE equal (same arithmetic, same order); reference llama/model.py:428-470 at the new rows."""
-    dt = torch.bfloat16
-    Dh, A, F = 128, 10, 10
-    D = H * Dh
-    if not ops.decode_token_ok(B, S, H, Dh, Hf, A, dt):
-        pytest.skip("shape not served by the persistent token kernel")
-    cos, sin = ref_cpu.rope_tables(2 * S, Dh, torch.float32)
-    rope = (dev(cos), dev(sin))
-    layers = []
-    for i in range(L):
-        sd = 100 * i
-        w1, w3 = rnd(Hf, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 4), rnd(Hf, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 5)
-        layers.append(dict(
-            an=dev(rnd(D, dtype=dt, seed=sd + 1) + 1), wqkv=dev(rnd(3 * D, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 2)),
-            wo=dev(rnd(D, D, dtype=dt, scale=1 / math.sqrt(D), seed=sd + 3)), fn=dev(rnd(D, dtype=dt, seed=sd + 6) + 1),
-            w13=dev(_ab16_rows(w1, w3)), w2=dev(rnd(D, Hf, dtype=dt, scale=1 / math.sqrt(Hf), seed=sd + 7)),
-            cache=rnd(B * S + A, 3 * D, dtype=dt, seed=sd + 8),
-            g1=dev(rnd(H, seed=sd + 9)), g2=dev(rnd(H, seed=sd + 10))))
-    x0 = rnd(B, D, dtype=dt, seed=77)
-    pos_t = dev(torch.tensor(pos, dtype=torch.int64))
-    vs = dev(torch.tensor([(7 if n % 3 else -1) for n in range(B)], dtype=torch.int32))
-    e = lambda *s: torch.empty(*s, dtype=dt, device=DEV)  # noqa: E731
-
-    def per_kernel():
-        caches = [dev(l["cache"]) for l in layers]
-        x, x2 = dev(x0), e(B, D)
-        xn, hn, h, o_row, qkv_row, ab, z = e(B, D), e(B, D), e(B, D), e(B, D), e(B, 3 * D), e(B, 2 * Hf), e(B, Hf)
-        for l, c in zip(layers, caches):
-            ops.rmsnorm_fwd(x, l["an"], xn, None, 1e-5, rows=B)
-            ops.gemm_nt(xn, l["wqkv"], qkv_row)
-            ops.attn_decode(qkv_row, c, o_row, l["g1"], l["g2"], vs, pos_t, rope, B, S, H, Dh, A, F, cache_rotated=True)
-            ops.gemm_nt(o_row, l["wo"], h, residual=x)
-            ops.rmsnorm_fwd(h, l["fn"], hn, None, 1e-5, rows=B)
-            ops.gemm_nt(hn, l["w13"], ab)
-            ops.swiglu_fwd(ab, z, B, Hf)
-            ops.gemm_nt(z, l["w2"], x2, residual=h)
-            x, x2 = x2, x
-        return x.cpu(), [c.cpu() for c in caches]
-
-    def persistent():
-        caches = [dev(l["cache"]) for l in layers]
-        table = torch.tensor([[l[k].data_ptr() for k in ("an", "wqkv", "wo", "fn", "w13", "w2")] + [c.data_ptr(), l["g1"].data_ptr(),
-                              l["g2"].data_ptr()] for l, c in zip(layers, caches)], dtype=torch.int64, device=DEV)
-        x, x_out = dev(x0), e(B, D)
-        scratch = ops.decode_scratch(L, B, H, Dh, Hf, DEV)
-        ws = ops.decode_workspace(DEV)
-        ops.decode_token(table, L, x, x_out, scratch, vs, pos_t, rope, B, S, H, Dh, Hf, A, F, 1e-5, True, ws)
-        torch.cuda.synchronize()
-        assert int(ws[16:24].view(torch.int64)[0].item()) == 0, "a grid barrier timed out"
-        assert torch.equal(x.cpu().view(torch.int16), x0.view(torch.int16))      # the input rows are read only
-        return x_out.cpu(), [c.cpu() for c in caches]
-
-    want, got = per_kernel(), persistent()
-    assert torch.isfinite(want[0].float()).all()
-    assert torch.equal(got[0].view(torch.int16), want[0].view(torch.int16))
-    for a, b in zip(got[1], want[1]):
-        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
-    again = persistent()
-    assert torch.equal(again[0].view(torch.int16), got[0].view(torch.int16))

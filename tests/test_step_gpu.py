@@ -26,7 +26,9 @@ GOLDEN_CASES = ["tiny_vqa", "tiny_all", "tiny_cold", "small_all", "7b_l2_all", "
                 "7b_l2_b8_vqa", "7b_l2_b8_all", "7b_l2_s650_all", "13b_l2_all",
                 "tiny_all_peaked", "7b_l2_b8_vqa_peaked", "7b_l2_b8_all_peaked", "7b_full_all_peaked",
                 "7b_l2_s650_all_peaked", "13b_l2_all_peaked", "7b_full_b8_vqa_peaked", "7b_full_s650_vqa_peaked",
-                "7b_l2_s256_b4_all_peaked", "7b_l2_s384_b2_all_peaked"]
+                "7b_l2_s256_b4_all_peaked", "7b_l2_s384_b2_all_peaked",
+                # round 5: C3's and C5's shapes 16 layers deep (reference-held; llama/model.py:338-345 is the loop they pin)
+                "7b_l16_b8_all_peaked", "13b_l16_all_peaked"]
 # against the reference's golden the bf16 build measures (profiles/r02_parity_vs_golden.log): losses <= 3.1e-4, sampled
 # logits <= 7.5e-3 of the logit range, gradients <= 2.0e-2; the bounds below leave about 2.5x
 BF16_TOL = dict(loss=5e-3, logits=2e-2, layer=3e-2, grad=5e-2)
@@ -64,7 +66,8 @@ BF16_MIN_DECIDED = {"small_all": 0.40, "7b_l2_all": 0.49, "7b_full_all": 0.20, "
                     "7b_l2_b8_vqa_peaked": 0.95, "7b_l2_b8_all_peaked": 0.95, "7b_full_all_peaked": 0.95,
                     "7b_l2_s650_all_peaked": 0.95, "13b_l2_all_peaked": 0.95,
                     "7b_full_b8_vqa_peaked": 0.95, "7b_full_s650_vqa_peaked": 0.95,
-                    "7b_l2_s256_b4_all_peaked": 0.95, "7b_l2_s384_b2_all_peaked": 0.95}
+                    "7b_l2_s256_b4_all_peaked": 0.95, "7b_l2_s384_b2_all_peaked": 0.95,
+                    "7b_l16_b8_all_peaked": 0.95, "13b_l16_all_peaked": 0.95}
 
 
 @pytest.mark.parametrize("case", list(BF16_MIN_DECIDED))

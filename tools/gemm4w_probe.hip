@@ -112,7 +112,6 @@ static float dispatch(int nbt, const PArgs& a, int reps, int cap, double* c = nu
     case 16: return run<16>(a, reps, cap, c, l);
     case 12: return run<12>(a, reps, cap, c, l);
     case 11: return run<11>(a, reps, cap, c, l);
-    case 8: return run<8>(a, reps, cap, c, l);
     default: printf("unsupported NBT %d\n", nbt); exit(1);
   }
 }

@@ -576,7 +576,7 @@ template <int NBT> struct Ring4Asm;
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "flipped-vqa_amd", "csrc", "gemm4w_asm.h")
-    widths = [int(x) for x in sys.argv[1:]] or [16, 12, 11]
+    widths = [int(x) for x in sys.argv[1:]] or [16, 14, 13, 12, 11]       # the widths gemm4w.hip dispatches
     with open(out, "w") as f:
         f.write(HEADER)
         for n in widths:

@@ -4,7 +4,7 @@
 Needs the diagnostic build of the library (`-DFVQA_SK_CLOCK`: s_memtime / s_memrealtime stamped around the ring loop of
 every workgroup's first segment, one slice of a 512-launch ring per launch):
 
-    python tools/sk_clock.py --build            # here (hipcc cross-compiles): writes fvqa/libfvqa_clock.so
+    python tools/sk_clock.py --build            # here (hipcc cross-compiles): writes tools/bin/libfvqa_clock.so
     python tools/sk_clock.py [--mode step|b2b]  # on the GPU box (it loads that build through FVQA_LIB)
 
 mode step: the benchmarked C2 training step (bench.py's model and batches) runs back to back for >= --seconds, then the
@@ -23,12 +23,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "flipped-vqa_amd")
 sys.path.insert(0, PKG)
 sys.path.insert(0, ROOT)
-CLOCK_LIB = os.path.join(PKG, "fvqa", "libfvqa_clock.so")
+CLOCK_LIB = os.path.join(ROOT, "tools", "bin", "libfvqa_clock.so")      # (git-ignored; NOT beside the product library)
 RING = 512
 
 
 def build():
     from fvqa import build as fb
+    os.makedirs(os.path.dirname(CLOCK_LIB), exist_ok=True)
     print(fb.build(out=CLOCK_LIB, defines=["FVQA_SK_CLOCK"]))
 
 

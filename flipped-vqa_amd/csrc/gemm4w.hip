@@ -60,9 +60,9 @@ int dispatch4(const G4Args& a, int out_dtype, int epilogue, hipStream_t st) {
 // Estimated launch time (us) of an (M, N, K) problem with tiles of 16*nbt columns on n_cu CUs, fitted to the launch times of
 // the C2 projections on an MI355X (profiles/r04_gemm4w.log): whole rounds of tiles; a round's time grows with the tile width
 // and, sub-linearly, with the number of busy CUs (the chip holds a higher clock with fewer of them: 0.865 of the full-chip
-// tile time with 192 busy, 0.82 with 172); an epilogue term per round; a rider streams its weight rows at ~23 GB/s per light
-// workgroup from the start of the last round (measured 22-25 under the load of the busy CUs) and is a launch of its own
-// (~3.2 TB/s + 10 us) when fewer than 8 workgroups are light.
+// tile time with 192 busy, 0.82 with 172); an epilogue term per round; a rider streams its weight rows in whole passes of 32
+// columns at ~17.5 GB/s per light workgroup from the start of the last round (re-fitted in round 5 against the width survey
+// of tools/gemm4w_widths.py) and is a launch of its own (~3.2 TB/s + 10 us) when fewer than 8 workgroups are light.
 static double g4_cost_us(int M, int N, int K, int nbt, int epilogue, int out_dtype, const fvqa_sk_rider* rider, int n_cu,
                          int* light_out) {
   const int tm = (M + 255) / 256, tn = (N + 16 * nbt - 1) / (16 * nbt);
@@ -82,8 +82,16 @@ static double g4_cost_us(int M, int N, int K, int nbt, int epilogue, int out_dty
   if (rider) {
     const double bytes = 2.0 * rider->N * (double)rider->K;
     if (light >= 8) {
-      const double t_r = head + bytes / (light * 23.0e3) + 3.0;
+      // a light workgroup takes whole passes of two 16-column strips (32 x K weight elements) at ~17.5 GB/s: round 5's width
+      // survey (profiles/r05_gemm4w_widths.log) — S = 384: 35 light workgroups x 4 passes of 512 KiB finished 120 us after the
+      // first round, 30 us behind the tiles (the round-4 figure, 23 GB/s without the pass quantum, had it level with them and
+      // picked that width: 11.5 % slower than the best one)
+      const int pairs = (rider->N + 31) / 32;
+      const int passes = (pairs + light - 1) / light;
+      const double t_r = head + passes * (2.0 * 32 * (double)rider->K) / 17.5e3 + 3.0;
+      const double main_us = total;
       if (t_r > total) total = t_r;
+      total += 0.01 * main_us;                        // between rider-bound widths, the one whose tiles finish earlier
     } else {
       total += 10.0 + bytes / 3.2e6;
     }

@@ -44,13 +44,21 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nwg) {     // consecutive 
 
 // Slot (workgroup after xcd_chunk) -> position k in a round's tile list. Groups of `tm` consecutive positions (the m tiles
 // of one weight panel) go to ONE XCD, consecutive groups to consecutive XCDs, so that the positions past the end of the
-// last round — the light workgroups — are spread over all XCDs. Identity when the XCD share is not a multiple of tm.
+// last round — the light workgroups, and with them the idle share of a partly filled round — are spread over all XCDs.
+// An XCD's share of `per` slots holds q = per / tm whole groups; the r = per - q tm slots left over take the positions behind
+// all whole groups, r consecutive ones per XCD (round 5: with tm = 6 or 9 — 13B at 1536 rows, S = 384 — the map used to be the
+// identity, which put every light workgroup and the whole idle share of the last round on the last one or two XCDs).
+// Bijective on [0, grid) for every tm; identity when grid is not a multiple of 8 or tm exceeds the share.
 __device__ __forceinline__ int slot_to_pos(int slot, int grid, int tm) {
   const int per = grid >> 3;
-  if ((grid & 7) || per % tm) return slot;
+  if (grid & 7) return slot;
+  const int q = per / tm, r = per - q * tm;
   const int x = slot / per, p = slot - x * per;
-  const int gi = p / tm;
-  return (gi * 8 + x) * tm + (p - gi * tm);
+  if (p < q * tm) {
+    const int gi = p / tm;
+    return (gi * 8 + x) * tm + (p - gi * tm);
+  }
+  return 8 * q * tm + x * r + (p - q * tm);
 }
 
 __device__ __forceinline__ void unpack8(const uint4& q, float (&v)[8]) {

@@ -65,6 +65,7 @@ class DataParallel(torch.nn.Module):
         self.module = module
         self.group = group
         self.comm_events = None
+        self.last_sync_ordering = None
         self.broadcast_params()
 
     def forward(self, *a, **k):
@@ -105,6 +106,20 @@ class DataParallel(torch.nn.Module):
                 flat.err_lane.copy_(word.view(torch.int64) != 0)
             else:
                 flat.err_lane.zero_()
+        # Stream ordering made explicit (torch orders a collective behind the CURRENT stream only: ProcessGroupNCCL makes its
+        # own stream wait for an event of the current one, and the blocking form makes the current stream wait for the
+        # collective): when the backward produced the gradients on another stream than the one the optimizer step runs on,
+        # the current stream first waits for the producer — so the all-reduce, and the unscale kernel queued behind it on the
+        # current stream, see finished gradients. `last_sync_ordering` records which case the last call was (tests).
+        self.last_sync_ordering = "host"
+        if flat.flat_grad.is_cuda:
+            cur = torch.cuda.current_stream(flat.flat_grad.device)
+            prod = getattr(flat, "producer_stream", None)
+            if prod is not None and prod != cur:
+                cur.wait_stream(prod)
+                self.last_sync_ordering = "waited_for_producer_stream"
+            else:
+                self.last_sync_ordering = "same_stream"
         ev = self.comm_events
         if ev is not None and flat.flat_grad.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

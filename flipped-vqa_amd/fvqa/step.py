@@ -353,6 +353,9 @@ class StepEngine:
         B, S, vs, labels = sv["B"], sv["S"], sv["vs"], sv["labels"]
         F, D, V, A, H, Dh, Hf, L = self.F, self.D, self.V, self.A, self.H, self.Dh, self.Hf, self.L
         n_seq, R, Ra = ar.n_seq, ar.R, ar.Ra
+        # the stream the gradients are produced on (the autograd thread's current stream): DataParallel.sync_grads orders the
+        # gradient all-reduce behind it explicitly when the optimizer step runs on another stream
+        grads.producer_stream = torch.cuda.current_stream(ar.gscale.device)
         ar.gscale.copy_(g_losses)
         ar.d_tok.zero_()
         has_qav = "qav" in self.tasks

@@ -15,6 +15,30 @@ import torch.distributed as dist  # noqa: E402
 
 N_STEPS, INF_STEP, INF_RANK = 5, 1, 1
 ERR_STEP, ERR_RANK = 3, 0          # a timed-out split-K exchange (persistent-GEMM error word) on ONE rank
+SIDE_STEP = 2                      # forward + backward on a side stream, optimizer step on the default one
+
+
+def scaler_scale(scaler, loss):
+    scaler._lazy(loss.device)
+    return scaler._scale
+
+
+def finish_step(scaler, opt):
+    """What NativeScalerWithGradNormCount.__call__ does after its backward (util/misc.py; reference util/misc.py:259-273):
+    gradient sync, unscale + norm, AdamW, scale update — on the CURRENT stream."""
+    from fvqa import ops
+    flat = opt.flat
+    r = opt.grad_sync()
+    div = r if isinstance(r, int) and r > 1 else 1
+    n_seg = flat.seg_off.numel() - 1
+    if getattr(scaler, "_ws", None) is None or scaler._seg_sq.numel() < n_seg:
+        scaler._seg_sq = torch.empty(n_seg, dtype=torch.float32, device=scaler._dev)
+        scaler._ws = torch.empty(ops.grad_norm_workspace(n_seg), dtype=torch.uint8, device=scaler._dev)
+    ops.grad_unscale_norm(flat.flat_grad, flat.seg_off, scaler._scale, scaler._seg_sq, scaler._found, scaler._norm, scaler._ws,
+                          grad_div=float(div), gemm_err=ops.gemm_error_word(scaler._dev), err_lane=getattr(flat, "err_lane", None))
+    opt.step(found_inf=scaler._found)
+    ops.scaler_update(opt.step_dev, scaler._scale, scaler._tracker, scaler._found, scaler.growth_factor, scaler.backoff_factor,
+                      scaler.growth_interval)
 
 
 def batch_seed(rank, world, i):
@@ -121,11 +145,27 @@ def main():
         return net.sync_grads()
 
     opt.grad_sync = sync
+    # SIDE_STEP: forward + backward run on a SIDE stream, the gradient all-reduce + unscale + AdamW on the default stream with no
+    # host synchronisation in between — correct only because sync_grads makes the current stream wait for the stream the
+    # gradients were produced on (fvqa/parallel.py); every other step runs everything on one stream
+    side = torch.cuda.Stream(device=device_index)
+    trace["ordering"] = []
     for i in range(N_STEPS):
         step_no["i"] = i
         opt.zero_grad()
-        a, b, c = net(synth.make_batch(cfg, seed=batch_seed(rank, world, i)))
-        scaler(a + b + c, opt, parameters=None, update_grad=True)
+        batch = synth.make_batch(cfg, seed=batch_seed(rank, world, i))
+        if i == SIDE_STEP:
+            side.wait_stream(torch.cuda.current_stream(device_index))
+            with torch.cuda.stream(side):
+                a, b, c = net(batch)
+                loss = a + b + c
+                (loss * scaler_scale(scaler, loss)).sum().backward()
+            # (the loss scaler's own backward call is replaced by the one above: the step below only syncs, unscales and steps)
+            finish_step(scaler, opt)
+        else:
+            a, b, c = net(batch)
+            scaler(a + b + c, opt, parameters=None, update_grad=True)
+        trace["ordering"].append(net.last_sync_ordering)
         torch.cuda.synchronize()
         trace[f"p{i}"] = flat.flat.detach().cpu().clone()
         trace[f"scale{i}"] = float(scaler._scale.item())

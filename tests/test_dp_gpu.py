@@ -65,6 +65,13 @@ def test_two_ranks_stay_bitwise_equal_and_match_single_process_average(tmp_path)
     assert torch.equal(t0[f"p{e}"], t0[f"p{e - 1}"]) and t0[f"scale{e}"] == t0[f"scale{e - 1}"]
     assert t0[f"step{e}"] == t0[f"step{e - 1}"]
     assert not torch.equal(t0[f"p{e + 1}"], t0[f"p{e}"])            # training resumes afterwards
+    # stream ordering of the gradient all-reduce, explicit and asserted (round-4 verdict #7): on SIDE_STEP the forward + backward
+    # ran on a side stream and the all-reduce + unscale + AdamW on the default one with no host synchronisation in between —
+    # sync_grads made the current stream wait for the producer stream (and the result below still equals the one-process
+    # average, i.e. no gradient was read before it was finished); every other step ran on one stream
+    for t in (t0, t1):
+        want = ["waited_for_producer_stream" if i == W.SIDE_STEP else "same_stream" for i in range(W.N_STEPS)]
+        assert t["ordering"] == want, t["ordering"]
 
     # ONE process doing both shards and the mean itself (what DDP's all-reduce computes)
     cfg = synth.preset("tiny", vaq=True, qav=True)

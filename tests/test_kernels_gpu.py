@@ -321,6 +321,25 @@ def test_gemm4w_every_width(nbt, epi):
     assert ops.gemm_error() == 0
 
 
+def test_gemm4w_chooser_picks_a_width_within_tolerance():
+    """The tile-width cost model (csrc/gemm4w.hip g4_cost_us / fvqa_gemm4w_choose) against MEASURED widths on the projections
+    of the benchmarked step (C2: q|k|v + RoPE, W1|W3 + SwiGLU + rider, dH W2^T + SwiGLU' + rider, LM head): every legal width
+    timed interleaved on this device (tools/gemm4w_widths.py survey()), the pick must be within 5 % of the fastest (the tool's
+    full table over C2-C5 and the S = 256 / 384 recipes, at 3 %, is profiles/r05_gemm4w_widths.log). A pick that loses by more
+    means the model's constants no longer describe the kernel."""
+    import io
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gemm4w_widths as W
+    buf = io.StringIO()
+    rows = W.survey(["c2"], rounds=5, reps=6, tol=0.05, out=buf)
+    print(buf.getvalue())
+    assert len(rows) == 4, [r["label"] for r in rows]            # the four whole-tile projections of a C2 step
+    for r in rows:
+        assert r["pick_over_best"] <= 1.05, (r["label"], r["pick"], r["best"], r["times"])
+
+
 @pytest.mark.parametrize("M,N,K,resid", [(1000, 4000, 4096, False), (1000, 4000, 4096, True), (520, 4088, 2048, True),
                                          (1024, 4096, 11008, True)])
 def test_gemm4w_split_k_on_ragged_tiles(M, N, K, resid):

@@ -325,7 +325,8 @@ def main():
     ap.add_argument("--seq_len", type=int, default=128)
     ap.add_argument("--vaq", action="store_true")
     ap.add_argument("--qav", action="store_true")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="storage type of activations / frozen weights: bf16 (BASELINE configs), fp16 (the reference's own), fp32 (exact)")
     ap.add_argument("--n_layers", type=int, default=0, help="debug only: reduced depth (marks the line invalid)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_other_configs", action="store_true",
@@ -572,7 +573,7 @@ def main():
             per, gemm_ms, flops_step, n_launch, n_timed = per_d, gemm_ms_dense, flops_dense, n_dense, n_timed_d
             stride_used, ms_pass, gemm_ms_raw = 1, ms_dense, gemm_ms_raw_dense
         if gemm_ms > 0:
-            peak = MFMA_BF16_PEAK if a.dtype == "bf16" else 157.3e12
+            peak = MFMA_BF16_PEAK if a.dtype in ("bf16", "fp16") else 157.3e12      # (f16 MFMA = bf16 MFMA rate)
             events_ms = n_timed / a.steps * probe_overhead_us * 1e-3
             non_gemm_ms = ms_pass - gemm_ms - events_ms        # everything of a step that is not this kernel (incl. kernel boundaries)
             achieved = flops_step / (gemm_ms * 1e-3)
@@ -626,7 +627,7 @@ def main():
         L = len(model.engine_layer_ids())
         Hf = model.layers[0].feed_forward.w1.weight.shape[0]
         fl = step_flops(p.dim, p.n_heads, L, Hf, model.vocab_size, a.batch_size, a.seq_len, 10, 10, tasks)
-        peak = MFMA_BF16_PEAK if a.dtype == "bf16" else 157.3e12
+        peak = MFMA_BF16_PEAK if a.dtype in ("bf16", "fp16") else 157.3e12      # (f16 MFMA = bf16 MFMA rate)
         out = {
             # BASELINE.json's metric string verbatim for its workload; `value` is the samples/s part, the
             # "MFMA % of peak" part is step_roofline.frac (whole step) and roofline.frac (dominant kernel)

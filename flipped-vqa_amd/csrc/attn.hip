@@ -489,7 +489,7 @@ static bool use_mfma_attention() {
 }
 
 // 1 when fvqa_attn_fwd/bwd of this dtype apply RoPE themselves (cos_t/sin_t arguments): the bf16 MFMA build
-extern "C" int fvqa_attn_rope_fused(int dtype) { return dtype == FVQA_BF16 && use_mfma_attention() ? 1 : 0; }
+extern "C" int fvqa_attn_rope_fused(int dtype) { return dtype == FVQA_H16 && use_mfma_attention() ? 1 : 0; }
 
 extern "C" int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_t, const float* gate1,
                              const float* gate2, const int32_t* vstart, const float* cos_t, const float* sin_t,
@@ -504,13 +504,13 @@ extern "C" int fvqa_attn_fwd(const void* qkv, void* o, float* lse_a, float* lse_
   const int nqb = (seq_len + TILE - 1) / TILE;
   dim3 grid(nqb, n_heads, n_seq), block(256);
   const size_t lds = (size_t)(2 * TILE + 2 * adapter_len) * DH * sizeof(float);
-  if (dtype == FVQA_BF16 && use_mfma_attention()) {
+  if (dtype == FVQA_H16 && use_mfma_attention()) {
     fvqa_attn_fwd_mfma(qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, n_seq, seq_len, n_heads, adapter_len,
                        max_feats, (hipStream_t)stream);
     FVQA_CHECK_LAUNCH();
     return FVQA_OK;
   }
-  if (dtype == FVQA_BF16)
+  if (dtype == FVQA_H16)
     hipLaunchKernelGGL(attn_fwd_k<bf16_t>, grid, block, lds, (hipStream_t)stream, (const bf16_t*)qkv, (bf16_t*)o,
                        lse_a, lse_t, gate1, gate2, vstart, n_seq, seq_len, n_heads, adapter_len, max_feats);
   else
@@ -552,7 +552,7 @@ static int attn_bwd_impl(const void* d_o, const void* qkv, const void* o, const 
   dim3 block(256);
   const size_t lds_q = (size_t)(2 * TILE + 2 * adapter_len) * DH * sizeof(float);
   const size_t lds_kv = (size_t)(2 * TILE * DH + 2 * TILE) * sizeof(float);
-  if (dtype == FVQA_BF16 && use_mfma_attention()) {
+  if (dtype == FVQA_H16 && use_mfma_attention()) {
     const int reduced = fvqa_attn_bwd_mfma(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, cos_t, sin_t, dqkv, dgate1,
                                            dgate2, delta_a, delta_t, gate_part, dka, dva, (int*)(wb + ws.arrive), n_seq,
                                            seq_len, n_heads, adapter_len, max_feats, st, prerotated);
@@ -562,7 +562,7 @@ static int attn_bwd_impl(const void* d_o, const void* qkv, const void* o, const 
     FVQA_CHECK_LAUNCH();
     return FVQA_OK;
   }
-  if (dtype == FVQA_BF16) {
+  if (dtype == FVQA_H16) {
     typedef bf16_t T;
     hipLaunchKernelGGL(attn_bwd_dq_k<T>, dim3(nqb, n_heads, n_seq), block, lds_q, st, (const T*)d_o, (const T*)qkv,
                        (const T*)o, lse_a, lse_t, gate1, gate2, vstart, (T*)dqkv, delta_a, delta_t, gate_part, n_seq,

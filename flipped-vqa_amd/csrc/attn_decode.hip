@@ -49,7 +49,7 @@ extern "C" int fvqa_attn_decode(const void* qkv_row, void* qkv_cache, void* o_ro
   if (((uintptr_t)qkv_row | (uintptr_t)qkv_cache | (uintptr_t)o_row) & 15) return FVQA_EALIGN;
   dim3 grid(n_heads, n_seq), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FVQA_BF16)
+  if (dtype == FVQA_H16)
     hipLaunchKernelGGL(attn_decode_k<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv_row, (bf16_t*)qkv_cache,
                        (bf16_t*)o_row, gate1, gate2, vstart, pos, cos_t, sin_t, n_seq, seq_len, n_heads, adapter_len,
                        max_feats, cache_rotated);

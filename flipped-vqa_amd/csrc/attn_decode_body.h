@@ -17,10 +17,10 @@ template <> struct Chunk<bf16_t> {
   static constexpr int CH = 8;
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     const uint4 q = *reinterpret_cast<const uint4*>(p);
-    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xFFFF0000u);
-    v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xFFFF0000u);
-    v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xFFFF0000u);
-    v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xFFFF0000u);
+    v[0] = h16_lo(q.x); v[1] = h16_hi(q.x);
+    v[2] = h16_lo(q.y); v[3] = h16_hi(q.y);
+    v[4] = h16_lo(q.z); v[5] = h16_hi(q.z);
+    v[6] = h16_lo(q.w); v[7] = h16_hi(q.w);
   }
 };
 template <> struct Chunk<float> {
@@ -111,7 +111,7 @@ __device__ __forceinline__ void attn_decode_body(const T* __restrict__ qkv_row, 
   auto load2 = [&](const T* vrow, float& a, float& b) {
     if constexpr (sizeof(T) == 2) {
       const unsigned u = *reinterpret_cast<const unsigned*>(vrow + d);
-      a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xFFFF0000u);
+      a = h16_lo(u); b = h16_hi(u);
     } else {
       const float2 u = *reinterpret_cast<const float2*>(vrow + d);
       a = u.x; b = u.y;

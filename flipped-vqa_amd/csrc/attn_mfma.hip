@@ -30,8 +30,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
 constexpr int DH = 128;
 constexpr int BQ = 128;                 // queries / keys per workgroup = rows per staged tile
 // Row pitch of the LDS tiles (bf16 elements). 288 bytes = 72 dwords: consecutive rows start 8 banks apart, so the 8 rows x 32
@@ -70,7 +68,7 @@ __device__ unsigned long long g_attn_stamps[1024 * 16];
 
 // D[4g+r][lane&15] += sum_k X[4g+r][k] * Y[lane&15][k]
 __device__ __forceinline__ f32x4 mma(const uint4& x, const uint4& y, f32x4 acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, x), __builtin_bit_cast(bf16x8_t, y),
+  return FVQA_MFMA_H16_16x16x32(__builtin_bit_cast(h16x8_t, x), __builtin_bit_cast(h16x8_t, y),
                                                  acc, 0, 0, 0);
 }
 __device__ __forceinline__ float across_g_max(float v) {      // over the 4 lanes that share lane&15
@@ -97,7 +95,7 @@ __device__ __forceinline__ uint4 rope8(const uint4& v, const float* c4, const fl
   unsigned o[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const float e = __uint_as_float(w[p] << 16), d = __uint_as_float(w[p] & 0xFFFF0000u);
+    const float e = h16_lo(w[p]), d = h16_hi(w[p]);
     o[p] = pack2(e * cc[p] - d * ss[p], e * ss[p] + d * cc[p]);
   }
   return make_uint4(o[0], o[1], o[2], o[3]);
@@ -453,8 +451,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_mfma_k(
     const unsigned tw[4] = {dof[ks].x, dof[ks].y, dof[ks].z, dof[ks].w}, uw[4] = {of.x, of.y, of.z, of.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      dtot += __uint_as_float(tw[k] << 16) * __uint_as_float(uw[k] << 16) +
-              __uint_as_float(tw[k] & 0xFFFF0000u) * __uint_as_float(uw[k] & 0xFFFF0000u);
+      dtot += h16_lo(tw[k]) * h16_lo(uw[k]) +
+              h16_hi(tw[k]) * h16_hi(uw[k]);
   }
   dtot = across_g_sum(dtot);
   const float g1 = tanhf(gate1[h]);
@@ -879,8 +877,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
       const unsigned uw[4] = {off[ks].x, off[ks].y, off[ks].z, off[ks].w};
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        dtot += __uint_as_float(tw[k] << 16) * __uint_as_float(uw[k] << 16) +
-                __uint_as_float(tw[k] & 0xFFFF0000u) * __uint_as_float(uw[k] & 0xFFFF0000u);
+        dtot += h16_lo(tw[k]) * h16_lo(uw[k]) +
+                h16_hi(tw[k]) * h16_hi(uw[k]);
     }
     dtot = across_g_sum(dtot);
     const float lsa = sLa[r16], lst = sLt[r16];
@@ -1160,9 +1158,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
         if (n0 + u < n_seq) { sk += tk[u]; sv += tv[u]; }
     }
     bf16_t* row = dqkv + ((size_t)n_seq * S + aa) * ld + h * DH + d;
-    row[0] = __float2bfloat16(0.f);
-    row[D] = __float2bfloat16(sk);
-    row[2 * D] = __float2bfloat16(sv);
+    row[0] = from_f32<bf16_t>(0.f);
+    row[D] = from_f32<bf16_t>(sk);
+    row[2 * D] = from_f32<bf16_t>(sv);
   }
   // gate sums: one coherent load per thread (all in flight together), then a fixed-order sum by thread 0
   float s1 = 0.f, s2 = 0.f;

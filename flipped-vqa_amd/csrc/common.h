@@ -7,7 +7,25 @@
 
 #define FVQA_WAVE 64
 
+// The 16-bit storage type of THIS build of the library. Every kernel source is compiled twice (fvqa/build.py):
+//   libfvqa_hip.so      bf16 storage (FVQA_H16; the production build of the BASELINE configs) + the exact-fp32 build
+//   libfvqa_hip_f16.so  -DFVQA_H16_F16: IEEE fp16 storage (FVQA_F16) — the reference's own storage type (llama_vqa.py:63 builds
+//                       the model under torch.cuda.HalfTensor; util/misc.py:253-273 GradScaler exists for it): the same kernels
+//                       with `bf16_t` = _Float16, v_mfma_f32_16x16x32_f16, fp16 pack / unpack. Same C ABI; each library accepts
+//                       its own 16-bit dtype code only (FVQA_H16) and the host binds the one the model's storage dtype needs.
+#ifdef FVQA_H16_F16
+typedef _Float16 bf16_t;                                   // (the name stays: "the 16-bit storage type of this build")
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));
+#define FVQA_H16 FVQA_F16
+#define FVQA_MFMA_H16_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define FVQA_MFMA_H16_ASM "v_mfma_f32_16x16x32_f16"
+#else
 typedef __hip_bfloat16 bf16_t;
+typedef __bf16 h16x8_t __attribute__((ext_vector_type(8)));
+#define FVQA_H16 FVQA_BF16
+#define FVQA_MFMA_H16_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define FVQA_MFMA_H16_ASM "v_mfma_f32_16x16x32_bf16"
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -19,6 +37,16 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
   } while (0)
 
 // ---- storage <-> fp32 ------------------------------------------------------------------
+// (the bf16-named helpers convert the build's 16-bit storage type: bf16 by shifts, fp16 by v_cvt)
+#ifdef FVQA_H16_F16
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  return __builtin_bit_cast(unsigned short, (_Float16)f);  // v_cvt_f16_f32: round-nearest-even, NaN preserved, overflow -> inf
+}
+// the two 16-bit values of a 32-bit word as floats
+__device__ __forceinline__ float h16_lo(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
+__device__ __forceinline__ float h16_hi(unsigned w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+#else
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
   return __uint_as_float(((unsigned)b) << 16);
 }
@@ -27,6 +55,9 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   bf16_t h = __float2bfloat16(f);
   return *reinterpret_cast<unsigned short*>(&h);
 }
+__device__ __forceinline__ float h16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+#endif
 
 template <typename T> struct Vec4;  // 4 consecutive elements
 template <> struct Vec4<float> {
@@ -41,8 +72,8 @@ template <> struct Vec4<float> {
 template <> struct Vec4<bf16_t> {
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
     uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+    v[0] = h16_lo(t.x); v[1] = h16_hi(t.x);
+    v[2] = h16_lo(t.y); v[3] = h16_hi(t.y);
   }
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
     uint2 t;
@@ -54,10 +85,18 @@ template <> struct Vec4<bf16_t> {
 
 template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+#ifdef FVQA_H16_F16
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }
+#else
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return __bfloat162float(x); }
+#endif
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+#ifdef FVQA_H16_F16
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (_Float16)x; }
+#else
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return __float2bfloat16(x); }
+#endif
 // round-trip through the storage type (the reference rounds at these points)
 template <typename T> __device__ __forceinline__ float round_to(float x) { return to_f32<T>(from_f32<T>(x)); }
 
@@ -108,5 +147,5 @@ static inline bool fvqa_attr_needed(std::atomic<unsigned long long>& done) {
   return true;
 }
 
-static inline int fvqa_dtype_ok(int dt) { return dt == FVQA_F32 || dt == FVQA_BF16; }
+static inline int fvqa_dtype_ok(int dt) { return dt == FVQA_F32 || dt == FVQA_H16; }   // (this build's 16-bit code only)
 static inline size_t fvqa_dtype_size(int dt) { return dt == FVQA_F32 ? 4 : 2; }

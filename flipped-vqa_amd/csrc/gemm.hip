@@ -18,8 +18,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
 constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int ROWB = 128;               // bytes of K per LDS row
@@ -30,8 +28,8 @@ template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   static constexpr int KELEMS = 64;
   static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                  __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    acc = FVQA_MFMA_H16_16x16x32(__builtin_bit_cast(h16x8_t, a),
+                                                  __builtin_bit_cast(h16x8_t, b), acc, 0, 0, 0);
   }
 };
 template <> struct Mma<float> {
@@ -257,7 +255,7 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
   if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
   if (variant != 0 && variant != 1 && variant != 2 && variant != 12 && variant != 13) return FVQA_EINVAL;
   if (M <= 0 || N <= 0 || K <= 0) return FVQA_ESHAPE;
-  const int ke = dtype == FVQA_BF16 ? 64 : 32;
+  const int ke = dtype == FVQA_H16 ? 64 : 32;
   if (K % ke) return FVQA_ESHAPE;
   const size_t es = fvqa_dtype_size(dtype);
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((size_t)lda * es & 15) || ((size_t)ldb * es & 15))
@@ -273,10 +271,10 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
                              nullptr, nullptr);
   if (swb) return FVQA_EALIGN;                                // that epilogue lives in the persistent kernel only
   // every row goes to the fp32 tail (m_split == 0): the decode-shape kernel accumulates straight into it
-  if (dtype == FVQA_BF16 && M <= 16 && (K % 256) == 0 && tail != nullptr && m_split == 0 && epilogue == FVQA_EPI_NONE &&
+  if (dtype == FVQA_H16 && M <= 16 && (K % 256) == 0 && tail != nullptr && m_split == 0 && epilogue == FVQA_EPI_NONE &&
       (variant == 0 || variant == 12))
     return launch_skinny<float>(A, B, tail, nullptr, M, N, K, lda, ldb, N, FVQA_EPI_SKINNY_ACC, st);
-  const bool skinny_ok = dtype == FVQA_BF16 && M <= 16 && (K % 256) == 0 && tail == nullptr &&
+  const bool skinny_ok = dtype == FVQA_H16 && M <= 16 && (K % 256) == 0 && tail == nullptr &&
                          (epilogue == FVQA_EPI_NONE || epilogue == FVQA_EPI_RESIDUAL);
   if (variant == 12 && !skinny_ok) return FVQA_ESHAPE;
   if (skinny_ok && (variant == 0 || variant == 12)) {       // decode shape: stream the weights once at HBM speed
@@ -284,7 +282,7 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
                                  : launch_skinny<bf16_t>(A, B, C, R, M, N, K, lda, ldb, ldc, epilogue, st);
   }
   const bool glds = variant != 1;
-  if (dtype == FVQA_BF16) {
+  if (dtype == FVQA_H16) {
     if (out_dtype == FVQA_F32)
       return glds ? launch_128<bf16_t, float, true>(A, B, C, R, tail, M, N, K, lda, ldb, ldc, m_split, epilogue, st)
                   : launch_128<bf16_t, float, false>(A, B, C, R, tail, M, N, K, lda, ldb, ldc, m_split, epilogue, st);
@@ -315,7 +313,7 @@ extern "C" int fvqa_gemm_nt_rider(const void* A, const void* B, void* C, const v
     if ((epilogue == FVQA_EPI_RESIDUAL || swb) && (!R || out_dtype != dtype)) return FVQA_EINVAL;
     if (swb && ldc != 2 * N) return FVQA_EINVAL;
     if (out_dtype != dtype && out_dtype != FVQA_F32) return FVQA_EINVAL;
-    const int ke = dtype == FVQA_BF16 ? 64 : 32;
+    const int ke = dtype == FVQA_H16 ? 64 : 32;
     const size_t es = fvqa_dtype_size(dtype);
     if (M <= 0 || N <= 0 || K <= 0 || (K % ke) || lda < K || ldb < K || ldc < N) return FVQA_ESHAPE;
     if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((size_t)lda * es & 15) || ((size_t)ldb * es & 15)) return FVQA_EALIGN;
@@ -353,22 +351,22 @@ extern "C" int fvqa_gemm_nt_rope(const void* A, const void* B, void* C, int M, i
                      ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace() && M >= 192 && N >= 256;
   int rode = 0, rc;
   if (sk_ok) {
-    rc = fvqa_gemm_sk_impl(A, B, C, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, FVQA_BF16, FVQA_BF16,
+    rc = fvqa_gemm_sk_impl(A, B, C, nullptr, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, FVQA_H16, FVQA_H16,
                            FVQA_EPI_ROPE, st, rider, &rode, nullptr, rope);
   } else {
     if (ldc != 3 * (rope->cols / 2)) return FVQA_ESHAPE;     // the row kernel takes fused q | k | v rows only
-    rc = fvqa_gemm_nt(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, M, FVQA_BF16, FVQA_BF16, FVQA_EPI_NONE, 0, workspace,
+    rc = fvqa_gemm_nt(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, M, FVQA_H16, FVQA_H16, FVQA_EPI_NONE, 0, workspace,
                       workspace_bytes, stream);
     if (!rc)
       rc = fvqa_rope_qk(C, rope->cos_t, rope->sin_t, M / rope->seq_len, rope->seq_len, rope->cols / 2 / rope->head_dim,
-                        rope->head_dim, 0, FVQA_BF16, stream);
+                        rope->head_dim, 0, FVQA_H16, stream);
   }
   if (rc || rode || !rider) return rc;
   if (rider->accumulate_f32)
     return fvqa_gemm_nt(rider->A, rider->B, nullptr, nullptr, (float*)rider->C, rider->M, rider->N, rider->K, rider->lda,
-                        rider->ldb, rider->ldc, 0, FVQA_BF16, FVQA_BF16, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+                        rider->ldb, rider->ldc, 0, FVQA_H16, FVQA_H16, FVQA_EPI_NONE, 0, nullptr, 0, stream);
   return fvqa_gemm_nt(rider->A, rider->B, rider->C, nullptr, nullptr, rider->M, rider->N, rider->K, rider->lda, rider->ldb,
-                      rider->ldc, rider->M, FVQA_BF16, FVQA_BF16, FVQA_EPI_NONE, 0, nullptr, 0, stream);
+                      rider->ldc, rider->M, FVQA_H16, FVQA_H16, FVQA_EPI_NONE, 0, nullptr, 0, stream);
 }
 
 static int swiglu_fwd_impl(const void* A, const void* B13, void* ab, void* z, int M, int hidden, int K, int lda, int ldb,
@@ -376,7 +374,7 @@ static int swiglu_fwd_impl(const void* A, const void* B13, void* ab, void* z, in
                            const fvqa_sk_rider* rider = nullptr) {
   if (!A || !B13 || !ab || !z || !fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
   const int N = 2 * hidden;
-  const int ke = dtype == FVQA_BF16 ? 64 : 32;
+  const int ke = dtype == FVQA_H16 ? 64 : 32;
   const size_t es = fvqa_dtype_size(dtype);
   if (M <= 0 || hidden <= 0 || (hidden % 16) || K <= 0 || (K % ke) || lda < K || ldb < K) return FVQA_ESHAPE;
   if (((uintptr_t)A & 15) || ((uintptr_t)B13 & 15) || ((uintptr_t)ab & 15) || ((uintptr_t)z & 15) ||

@@ -21,8 +21,6 @@
 #include "common.h"
 
 namespace fvqa_ring {
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 256;
@@ -31,8 +29,8 @@ template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   static constexpr int KE = 32;          // elements per MFMA k-step (64 bytes of a row)
   static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b),
-                                                  __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
+    acc = FVQA_MFMA_H16_16x16x32(__builtin_bit_cast(h16x8_t, b),
+                                                  __builtin_bit_cast(h16x8_t, a), acc, 0, 0, 0);
   }
 };
 template <> struct Mma<float> {

@@ -114,7 +114,7 @@ extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype,
                                   int n_cu) {
   static const char* env = getenv("FVQA_GEMM4W");
   if (env && env[0] == '0') return 0;
-  if (dtype != FVQA_BF16 || (out_dtype != FVQA_BF16 && out_dtype != FVQA_F32)) return 0;
+  if (dtype != FVQA_H16 || (out_dtype != FVQA_H16 && out_dtype != FVQA_F32)) return 0;
   if (out_dtype == FVQA_F32 && epilogue != FVQA_EPI_NONE) return 0;
   if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_ROPE &&
       epilogue != FVQA_EPI_SWIGLU_FWD_ST && epilogue != FVQA_EPI_SWIGLU_BWD_ST)

@@ -62,10 +62,10 @@ __device__ __forceinline__ int slot_to_pos(int slot, int grid, int tm) {
 }
 
 __device__ __forceinline__ void unpack8(const uint4& q, float (&v)[8]) {
-  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xFFFF0000u);
-  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xFFFF0000u);
-  v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xFFFF0000u);
-  v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xFFFF0000u);
+  v[0] = h16_lo(q.x); v[1] = h16_hi(q.x);
+  v[2] = h16_lo(q.y); v[3] = h16_hi(q.y);
+  v[4] = h16_lo(q.z); v[5] = h16_hi(q.z);
+  v[6] = h16_lo(q.w); v[7] = h16_hi(q.w);
 }
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   uint4 t;

@@ -70,10 +70,10 @@ __device__ __forceinline__ int xcd_chunk(int bid, int nwg) {     // consecutive 
 }
 
 __device__ __forceinline__ void unpack8(const uint4& q, float (&v)[8]) {
-  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xFFFF0000u);
-  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xFFFF0000u);
-  v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xFFFF0000u);
-  v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xFFFF0000u);
+  v[0] = h16_lo(q.x); v[1] = h16_hi(q.x);
+  v[2] = h16_lo(q.y); v[3] = h16_hi(q.y);
+  v[4] = h16_lo(q.z); v[5] = h16_hi(q.z);
+  v[6] = h16_lo(q.w); v[7] = h16_hi(q.w);
 }
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   uint4 t;
@@ -658,7 +658,14 @@ int launch_sk4(const SkArgs& a, hipStream_t st) {
   return FVQA_OK;
 }
 
+// Launch epochs of THIS library. libfvqa_hip.so and libfvqa_hip_f16.so may serve one process (and then share the stream's
+// workspace, its flags and its error word): flags are compared for EQUALITY with the launch's epoch, so disjoint ranges keep
+// a flag value left by the other library from ever matching.
+#ifdef FVQA_H16_F16
+std::atomic<unsigned long long> g_epoch{1ull << 62};
+#else
 std::atomic<unsigned long long> g_epoch{0};
+#endif
 
 template <typename T, typename TO, int EPI>
 int launch_sk(const SkArgs& a, hipStream_t st) {
@@ -703,7 +710,7 @@ extern "C" size_t fvqa_gemm_sk_workspace(void) {
 extern "C" int fvqa_gemm_sk_describe(int M, int N, int K, int dtype, int n_cu, int32_t* plan_out, int team,
                                      int32_t* segs_out, int max_segs) {
   if (M <= 0 || N <= 0 || K <= 0 || !fvqa_dtype_ok(dtype) || n_cu <= 0) return FVQA_EINVAL;
-  const int wide = dtype == FVQA_BF16 ? 64 : 32;
+  const int wide = dtype == FVQA_H16 ? 64 : 32;
   if (K % wide) return FVQA_ESHAPE;
   const fvqa_sk_plan p = fvqa_sk_make_plan(M, N, K, wide, n_cu);
   if (plan_out) {
@@ -740,7 +747,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
                       const fvqa_sk_rider* rider, int* rode, void* C2, const fvqa_sk_rope* rope) {
   if (rode) *rode = 0;
   if ((epilogue == FVQA_EPI_ROPE) != (rope != nullptr)) return FVQA_EINVAL;
-  if (rope && (dtype != FVQA_BF16 || out_dtype != FVQA_BF16 || !rope->cos_t || !rope->sin_t || rope->seq_len <= 0 ||
+  if (rope && (dtype != FVQA_H16 || out_dtype != FVQA_H16 || !rope->cos_t || !rope->sin_t || rope->seq_len <= 0 ||
                rope->head_dim <= 0 || (rope->head_dim % 8) || rope->cols < 0 || rope->cols > N || (rope->cols % rope->head_dim)))
     return FVQA_EINVAL;
   if (!ws || ws_bytes < fvqa_gemm_sk_workspace() || ((uintptr_t)ws & 255)) return FVQA_EALIGN;
@@ -754,7 +761,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   SkArgs a;
   a.A = A; a.B = B; a.C = C; a.R = R; a.C2 = C2;
   if ((epilogue == FVQA_EPI_SWIGLU_FWD || epilogue == FVQA_EPI_SWIGLU_FWD_ST) && (!C2 || (N & 31) || ((uintptr_t)C2 & 15) || out_dtype != dtype)) return FVQA_EINVAL;
-  if (dtype == FVQA_BF16) {
+  if (dtype == FVQA_H16) {
     // Outputs wide enough to fill the chip with whole tiles go to the 4-wave kernel (gemm4w.hip: one wave per SIMD, tile
     // width chosen per problem); a launch this kernel would split along K in full (N = 4096 outputs at M = 1024: 64 tiles
     // for 256 CUs) stays here.
@@ -781,7 +788,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   a.slabs = (float*)((char*)ws + SYNC_BYTES);
   a.stamps = (u64*)((char*)ws + SYNC_BYTES + (size_t)256 * SLAB_FLOATS * sizeof(float));
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.plan = fvqa_sk_make_plan(M, N, K, dtype == FVQA_BF16 ? 64 : 32, n_cu < 256 ? n_cu : 256);
+  a.plan = fvqa_sk_make_plan(M, N, K, dtype == FVQA_H16 ? 64 : 32, n_cu < 256 ? n_cu : 256);
   if (a.plan.n_teams * a.plan.ts > 256 || a.plan.n_teams * a.plan.ts > n_cu) return FVQA_ESHAPE;
   a.epoch = g_epoch.fetch_add(1) + 1;
 #ifdef FVQA_SK_CLOCK
@@ -792,7 +799,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   a.rope_S = rope ? rope->seq_len : 1; a.rope_cols = rope ? rope->cols : 0; a.rope_hp = rope ? rope->head_dim / 2 : 1;
   const int idle = (n_cu < 256 ? n_cu : 256) - a.plan.n_teams * a.plan.ts;
   static const bool ride = !(getenv("FVQA_RIDER") && getenv("FVQA_RIDER")[0] == '0');   // tuning: FVQA_RIDER=0 keeps riders as own launches
-  if (ride && rider && dtype == FVQA_BF16 && idle >= 16 && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 &&
+  if (ride && rider && dtype == FVQA_H16 && idle >= 16 && rider->M >= 1 && rider->M <= 16 && (rider->K % 256) == 0 &&
       rider->N > 0 && rider->A && rider->B && rider->C) {
     const int strips = (rider->N + 15) / 16;
     a.rider = SkRider{rider->A, rider->B, rider->C, rider->M, rider->N, rider->K, rider->lda, rider->ldb, rider->ldc,
@@ -803,7 +810,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
   // 4-wave main loop (FVQA_GEMM4W_SK=0: the 8-wave kernel, for A/B runs)
   static const bool sk4 = !(getenv("FVQA_GEMM4W") && getenv("FVQA_GEMM4W")[0] == '0') &&
                           !(getenv("FVQA_GEMM4W_SK") && getenv("FVQA_GEMM4W_SK")[0] == '0');
-  if (sk4 && SK_PACK24 && dtype == FVQA_BF16 && out_dtype == FVQA_BF16 && a.plan.full == 0 && a.plan.s >= 2 && a.plan.s <= 4 &&
+  if (sk4 && SK_PACK24 && dtype == FVQA_H16 && out_dtype == FVQA_H16 && a.plan.full == 0 && a.plan.s >= 2 && a.plan.s <= 4 &&
       (epilogue == FVQA_EPI_NONE || epilogue == FVQA_EPI_RESIDUAL) && (size_t)M * lda * 2 < 0x7fffffffull &&
       (size_t)N * ldb * 2 < 0x7fffffffull) {
     a.rope_hmask = 0;
@@ -820,7 +827,7 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     case FVQA_EPI_ROPE: return launch_sk<T, TO, FVQA_EPI_ROPE>(a, st);                        \
     default: return FVQA_EINVAL;                                                              \
   }
-  if (dtype == FVQA_BF16) {
+  if (dtype == FVQA_H16) {
     if (out_dtype == FVQA_F32) {
       if (epilogue != FVQA_EPI_NONE) return FVQA_EINVAL;
       return launch_sk<bf16_t, float, FVQA_EPI_NONE>(a, st);

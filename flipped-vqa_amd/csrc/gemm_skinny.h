@@ -16,7 +16,6 @@ template <typename TO, int EPI>
 __device__ __forceinline__ void skinny_strip(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                              TO* __restrict__ C, const bf16_t* __restrict__ R, int M, int N, int K,
                                              int lda, int ldb, int ldc, int n0, float (*part)[16][20]) {
-  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
   const int kw = K / 8;                                    // this wave's K range (K % 256 == 0)
@@ -36,8 +35,8 @@ __device__ __forceinline__ void skinny_strip(const bf16_t* __restrict__ A, const
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)                             // D[n = 4g+r][m = li]
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[u]),
-                                                    __builtin_bit_cast(bf16x8_t, af[u]), acc, 0, 0, 0);
+      acc = FVQA_MFMA_H16_16x16x32(__builtin_bit_cast(h16x8_t, bf[u]),
+                                                    __builtin_bit_cast(h16x8_t, af[u]), acc, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) part[w][li][4 * g + r] = acc[r];           // [wave][m][n]
@@ -68,7 +67,6 @@ template <typename TO, int EPI>
 __device__ __forceinline__ void skinny_strip2_4w(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                  TO* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int n0,
                                                  float (*part)[8][16][20]) {
-  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
   const int kw = K / 8;
@@ -112,8 +110,8 @@ __device__ __forceinline__ void skinny_strip2_4w(const bf16_t* __restrict__ A, c
       for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int u = 0; u < 4; ++u)                         // D[n = 4g+r][m = li]; every (strip, range) chain in k order
-          acc[s][e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bb[s][e][u]),
-                                                              __builtin_bit_cast(bf16x8_t, aa[e][u]), acc[s][e], 0, 0, 0);
+          acc[s][e] = FVQA_MFMA_H16_16x16x32(__builtin_bit_cast(h16x8_t, bb[s][e][u]),
+                                                              __builtin_bit_cast(h16x8_t, aa[e][u]), acc[s][e], 0, 0, 0);
   };
   ld(b0, a0, 0);
   for (int k0 = 0; k0 < kw; k0 += 256) {

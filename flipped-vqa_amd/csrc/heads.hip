@@ -378,7 +378,7 @@ extern "C" int fvqa_visual_proj_fwd(const float* video, const float* W, const fl
   // matrix cores instead, temporal embedding and cast included.
   if (in_dim % 64 == 0 && n_frames_total <= 128 && !(((uintptr_t)video | (uintptr_t)W) & 15)) {
     const dim3 g16((dim + 15) / 16);
-    if (dtype == FVQA_BF16)
+    if (dtype == FVQA_H16)
       hipLaunchKernelGGL(visual_proj_fwd_mfma_k<bf16_t>, g16, block, 0, st, video, W, temporal, vf_raw, (bf16_t*)vf_tok,
                          n_frames_total, max_feats, in_dim, dim);
     else
@@ -387,7 +387,7 @@ extern "C" int fvqa_visual_proj_fwd(const float* video, const float* W, const fl
     FVQA_CHECK_LAUNCH();
     return FVQA_OK;
   }
-  if (dtype == FVQA_BF16)
+  if (dtype == FVQA_H16)
     hipLaunchKernelGGL((visual_proj_fwd_k<bf16_t, 32>), grid, block, 0, st, video, W, temporal, vf_raw,
                        (bf16_t*)vf_tok, n_frames_total, max_feats, in_dim, dim);
   else
@@ -439,7 +439,7 @@ extern "C" int fvqa_ce_bwd(const float* logits, const int64_t* labels, const flo
   if (n_seq <= 0 || seq_len < 2 || vocab <= 0 || vocab % 4) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int rows = n_seq * seq_len;
-  if (dtype == FVQA_BF16)
+  if (dtype == FVQA_H16)
     hipLaunchKernelGGL(ce_bwd_k<bf16_t>, dim3(rows), dim3(256), 0, st, logits, labels, lse, loss_sum, gscale,
                        (bf16_t*)dlogits, seq_len, vocab, ignore_index);
   else
@@ -459,7 +459,7 @@ extern "C" int fvqa_qav_head_fwd(const void* xn, const float* vf_raw, const int6
   hipStream_t st = (hipStream_t)stream;
   const int rows = n_seq * seq_len;
   dim3 grid((rows + 3) / 4), block(256);
-  if (dtype == FVQA_BF16)
+  if (dtype == FVQA_H16)
     hipLaunchKernelGGL((qav_fwd_k<bf16_t, 16>), grid, block, 0, st, (const bf16_t*)xn, vf_raw, labels, probs, rowloss,
                        rows, seq_len, dim, max_feats, 1.f / tau);
   else
@@ -481,7 +481,7 @@ extern "C" int fvqa_qav_head_bwd(const void* xn, const float* vf_raw, const int6
   hipStream_t st = (hipStream_t)stream;
   const int rows = n_seq * seq_len;
   dim3 grid((rows + 3) / 4), block(256);
-  if (dtype == FVQA_BF16) {
+  if (dtype == FVQA_H16) {
     hipLaunchKernelGGL((qav_bwd_x_k<bf16_t, 16>), grid, block, 0, st, vf_raw, labels, probs, loss_sum, gscale,
                        (bf16_t*)dxn, rows, seq_len, dim, max_feats, 1.f / tau);
     hipLaunchKernelGGL(qav_bwd_v_k<bf16_t>, dim3(n_seq * max_feats), block, 0, st, (const bf16_t*)xn, labels, probs,

@@ -20,10 +20,10 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 }
 template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
   const uint4 t = *reinterpret_cast<const uint4*>(p);
-  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
-  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
-  v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xFFFF0000u);
-  v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xFFFF0000u);
+  v[0] = h16_lo(t.x); v[1] = h16_hi(t.x);
+  v[2] = h16_lo(t.y); v[3] = h16_hi(t.y);
+  v[4] = h16_lo(t.z); v[5] = h16_hi(t.z);
+  v[6] = h16_lo(t.w); v[7] = h16_hi(t.w);
 }
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
@@ -264,7 +264,7 @@ inline int grid_for(size_t n_items) {
 }  // namespace
 
 #define DISPATCH_T(dtype, ...)                         \
-  if ((dtype) == FVQA_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  if ((dtype) == FVQA_H16) { typedef bf16_t T; __VA_ARGS__; } \
   else { typedef float T; __VA_ARGS__; }
 
 static inline int norm_dims_ok(int rows, int dim) {

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST = 0, 1, 3, 6
 ABI_VERSION = 14
 
@@ -103,19 +103,37 @@ class FvqaLibraryError(RuntimeError):
     pass
 
 
-def lib_path() -> str:
-    return os.environ.get("FVQA_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfvqa_hip.so"))
+def kind_of(which=None) -> str:
+    """"f16" for the fp16-storage library (libfvqa_hip_f16.so), "bf16" for libfvqa_hip.so (bf16 and exact-fp32 storage).
+    `which`: None | "bf16" | "f16" | a dtype code (F32 / BF16 / F16) | a torch dtype."""
+    if which is None or which == "bf16":
+        return "bf16"
+    if which == "f16" or which == F16 or str(which) == "torch.float16":
+        return "f16"
+    return "bf16"
 
 
-_LIB: Optional[C.CDLL] = None
+def lib_path(which=None) -> str:
+    here = os.path.dirname(os.path.abspath(__file__))
+    if kind_of(which) == "f16":
+        return os.environ.get("FVQA_LIB_F16", os.path.join(here, "libfvqa_hip_f16.so"))
+    return os.environ.get("FVQA_LIB", os.path.join(here, "libfvqa_hip.so"))
 
 
-def load() -> C.CDLL:
-    """dlopen the library and bind every symbol of include/fvqa.h; raises if anything is missing."""
+_LIBS = {}
+_LIB: Optional[C.CDLL] = None          # the bf16 / fp32 library once loaded (kept for callers that look at it)
+
+
+def load(which=None) -> C.CDLL:
+    """dlopen the library that serves `which` (kind_of) and bind every symbol of include/fvqa.h; raises if anything is missing.
+    Both libraries are the same sources and the same ABI; they differ in the 16-bit storage type their kernels are built for and
+    reject the other's dtype code, so a tensor of the wrong 16-bit type fails loudly instead of being reinterpreted."""
     global _LIB
-    if _LIB is not None:
-        return _LIB
-    path = lib_path()
+    kind = kind_of(which)
+    lib = _LIBS.get(kind)
+    if lib is not None:
+        return lib
+    path = lib_path(kind)
     if not os.path.exists(path):
         raise FvqaLibraryError(
             f"{path} not found: build it with `python -m fvqa.build` (hipcc --offload-arch=gfx950). "
@@ -135,7 +153,9 @@ def load() -> C.CDLL:
     if v != ABI_VERSION:
         raise FvqaLibraryError(f"{path}: ABI version {v}, host expects {ABI_VERSION}")
     check_source_hash(lib, path)
-    _LIB = lib
+    _LIBS[kind] = lib
+    if kind == "bf16":
+        _LIB = lib
     return lib
 
 

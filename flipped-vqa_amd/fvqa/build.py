@@ -15,8 +15,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
-LIB = os.path.join(HERE, "libfvqa_hip.so")
+LIB = os.path.join(HERE, "libfvqa_hip.so")              # bf16 storage (+ the exact-fp32 build)
+LIB_F16 = os.path.join(HERE, "libfvqa_hip_f16.so")      # the same sources with IEEE fp16 as the 16-bit storage type (-DFVQA_H16_F16)
 OBJDIR = os.path.join(CSRC, "build")
+OBJDIR_F16 = os.path.join(CSRC, "build", "f16")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE, "-Wall", "-Wno-unused-function"]
 
@@ -68,11 +70,21 @@ LAST_BUILD = {"compiled": 0, "linked": False}        # what the last build() cal
 
 
 def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=()) -> str:
-    """defines: extra -D macros (tuning builds write to a different `out`, always from scratch).
+    """Builds BOTH libraries — libfvqa_hip.so (bf16 + fp32) and libfvqa_hip_f16.so (fp16 + fp32: every source compiled a second
+    time with -DFVQA_H16_F16, csrc/common.h) — and returns the path of the first.
+    defines: extra -D macros (tuning builds write to a different `out`, always from scratch).
     Every build compiles the hash of the kernel sources into the library (csrc/version.hip, -DFVQA_SOURCE_HASH), which
     fvqa/_lib.py checks at load time: an old binary next to newer sources does not load."""
     if defines:
         return _build_variant(out, defines, verbose)
+    n1, l1 = _build_one(force, verbose, LIB, OBJDIR, [])
+    n2, l2 = _build_one(force, verbose, LIB_F16, OBJDIR_F16, ["-DFVQA_H16_F16"])
+    LAST_BUILD.update(compiled=n1 + n2, linked=l1 or l2)
+    return LIB
+
+
+def _build_one(force, verbose, LIB, OBJDIR, extra):
+    FLAGS = globals()["FLAGS"] + list(extra)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
     shash = source_hash()
@@ -104,7 +116,7 @@ def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=())
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     open(os.path.join(OBJDIR, "version.o.hash"), "w").write(shash)
     for obj, key in keys.items():
@@ -112,11 +124,10 @@ def build(force: bool = False, verbose: bool = True, out: str = LIB, defines=())
     link = bool(jobs) or force or _stale(LIB, objs)
     if link:
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
-    LAST_BUILD.update(compiled=len(jobs), linked=link)
     if verbose:
-        print(f"[fvqa.build] {len(jobs)} of {len(objs)} objects compiled, library {'linked' if link else 'up to date'}, "
-              f"sources {shash[:12]}", flush=True)
-    return LIB
+        print(f"[fvqa.build] {os.path.basename(LIB)}: {len(jobs)} of {len(objs)} objects compiled, library "
+              f"{'linked' if link else 'up to date'}, sources {shash[:12]}", flush=True)
+    return len(jobs), link
 
 
 def _build_variant(out, defines, verbose):

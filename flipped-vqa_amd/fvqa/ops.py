@@ -11,16 +11,16 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST, F32
+from ._lib import BF16, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST, F16, F32
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
-_DTN = {torch.float32: "f32", torch.bfloat16: "bf16"}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_DTN = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
 
 def dt_code(dtype: torch.dtype) -> int:
     try:
         return _DT[dtype]
     except KeyError:
-        raise TypeError(f"storage dtype must be float32 or bfloat16, got {dtype}") from None
+        raise TypeError(f"storage dtype must be float32, bfloat16 or float16, got {dtype}") from None
 
 
 def _stream() -> int:
@@ -114,12 +114,14 @@ class gemm4w_width:
         self.nbt = int(nbt or 0)
 
     def __enter__(self):
-        self.prev = int(_lib.load().fvqa_gemm4w_force(self.nbt))
-        _need(self.prev >= 0, f"gemm4w_width: no tile width of {self.nbt} x 16 columns")
+        _lib.load()
+        self.prev = {k: int(lib.fvqa_gemm4w_force(self.nbt)) for k, lib in _lib._LIBS.items()}   # (every loaded library)
+        _need(all(v >= 0 for v in self.prev.values()), f"gemm4w_width: no tile width of {self.nbt} x 16 columns")
         return self
 
     def __exit__(self, *exc):
-        _lib.load().fvqa_gemm4w_force(self.prev)
+        for k, v in self.prev.items():
+            _lib._LIBS[k].fvqa_gemm4w_force(v)
         return False
 
 
@@ -168,7 +170,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, residual: Op
         _need(residual.dtype == a.dtype and out_dtype == a.dtype, "gemm_nt: residual dtype")
         _need(residual.shape[1] == N and residual.shape[0] >= min(M, m_split), "gemm_nt: residual shape")
         epi = EPI_RESIDUAL
-    lib = _lib.load()
+    lib = _lib.load(a.dtype)
     code = dt_code(a.dtype)
     if variant == 13:
         need = int(lib.fvqa_gemm_sk_workspace())
@@ -220,7 +222,7 @@ def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = 
         _need(rider_out.dtype == a.dtype, "gemm_nt_rider: rider_out dtype")
     rd = _lib.SkRider(rider_a.data_ptr(), rider_b.data_ptr(), rider_out.data_ptr(), M2, N2, K2, rider_a.stride(0),
                       rider_b.stride(0), rider_out.stride(0), 1 if acc else 0)
-    lib = _lib.load()
+    lib = _lib.load(a.dtype)
     ws = gemm_workspace(a.device, int(lib.fvqa_gemm_sk_workspace()))
     rc = lib.fvqa_gemm_nt_rider(_ptr(a), _ptr(b), _ptr(out), _ptr(R), M, N, K, a.stride(0), b.stride(0), ldc,
                                 dt_code(a.dtype), dt_code(out.dtype), epi, C.addressof(rd), _ptr(ws), ws.numel(),
@@ -232,20 +234,25 @@ def gemm_nt_rider(a, b, out, *, rider_a, rider_b, rider_out, accumulate: bool = 
 def gemm_timing_enable(on, stride: int = 1) -> None:
     """Measurement probe (include/fvqa.h fvqa_gemm_timing_enable): HIP events around every `stride`-th launch of
     the persistent GEMM kernel on its launch stream, under whichever schedule is running; the other launches are
-    counted only (gemm_timing_read returns -2 us for them)."""
-    _lib.check(_lib.load().fvqa_gemm_timing_enable(int(stride) if on else 0), "fvqa_gemm_timing_enable")
+    counted only (gemm_timing_read returns -2 us for them). Applies to every library loaded so far (the bf16 / fp32 one and,
+    once an fp16 model exists, the fp16 one: each keeps its own record)."""
+    _lib.load()
+    for lib in _lib._LIBS.values():
+        _lib.check(lib.fvqa_gemm_timing_enable(int(stride) if on else 0), "fvqa_gemm_timing_enable")
 
 
 def gemm_timing_read():
-    """-> list of (microseconds, flops, kind) per recorded launch; clears the record."""
+    """-> list of (microseconds, flops, kind) per recorded launch (all loaded libraries, one after the other); clears the record."""
     import ctypes as C
-    lib = _lib.load()
-    n = int(lib.fvqa_gemm_timing_read(0, None, None, None))
-    if n <= 0:
-        return []
-    us, fl, kd = (C.c_float * n)(), (C.c_double * n)(), (C.c_int * n)()
-    got = int(lib.fvqa_gemm_timing_read(n, C.cast(us, C.c_void_p), C.cast(fl, C.c_void_p), C.cast(kd, C.c_void_p)))
-    return [(float(us[i]), float(fl[i]), int(kd[i])) for i in range(min(n, got))]
+    out = []
+    for lib in list(_lib._LIBS.values()):
+        n = int(lib.fvqa_gemm_timing_read(0, None, None, None))
+        if n <= 0:
+            continue
+        us, fl, kd = (C.c_float * n)(), (C.c_double * n)(), (C.c_int * n)()
+        got = int(lib.fvqa_gemm_timing_read(n, C.cast(us, C.c_void_p), C.cast(fl, C.c_void_p), C.cast(kd, C.c_void_p)))
+        out += [(float(us[i]), float(fl[i]), int(kd[i])) for i in range(min(n, got))]
+    return out
 
 
 def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: torch.Tensor, st: bool = False, *,
@@ -261,7 +268,7 @@ def gemm_nt_swiglu_fwd(x: torch.Tensor, w13: torch.Tensor, ab: torch.Tensor, z: 
     _need(w13.shape[1] == K and N % 32 == 0 and x.dtype == w13.dtype == ab.dtype == z.dtype, "gemm_nt_swiglu_fwd: operands")
     _need(ab.shape[-1] == N and ab.numel() >= M * N and z.shape[-1] == N // 2 and z.numel() >= M * N // 2,
           "gemm_nt_swiglu_fwd: ab / z shape")
-    lib = _lib.load()
+    lib = _lib.load(x.dtype)
     ws = gemm_workspace(x.device, int(lib.fvqa_gemm_sk_workspace()))
     if rider_a is not None:
         _need(st, "gemm_nt_swiglu_fwd: a rider needs st=True")
@@ -310,7 +317,7 @@ def gemm_nt_swiglu_bwd(g: torch.Tensor, w2_t: torch.Tensor, ab: torch.Tensor, da
     _need(w2_t.shape[1] == K and g.dtype == w2_t.dtype == ab.dtype == dab.dtype, "gemm_nt_swiglu_bwd: operands")
     _need(ab.numel() >= M * 2 * N and dab.numel() >= M * 2 * N and ab.shape[-1] == 2 * N and dab.shape[-1] == 2 * N,
           "gemm_nt_swiglu_bwd: ab/dab shape")
-    lib = _lib.load()
+    lib = _lib.load(g.dtype)
     need = int(lib.fvqa_gemm_sk_workspace())                 # this epilogue lives in the persistent kernel
     ws = gemm_workspace(g.device, need)
     rc = lib.fvqa_gemm_nt(_ptr(g), _ptr(w2_t), _ptr(dab), _ptr(ab), None, M, N, K, K, K, 2 * N, M, dt_code(g.dtype),
@@ -330,7 +337,7 @@ def rmsnorm_fwd(x, w, y, rstd, eps: float, rows: Optional[int] = None):
     _need(w.numel() == dim and y.shape[-1] == dim, "rmsnorm_fwd: dim")
     _need(x.numel() >= rows * dim and y.numel() >= rows * dim, "rmsnorm_fwd: rows")
     _need(rstd is None or (rstd.dtype == torch.float32 and rstd.numel() >= rows), "rmsnorm_fwd: rstd")
-    rc = _lib.load().fvqa_rmsnorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(rstd), rows, dim, float(eps),
+    rc = _lib.load(x.dtype).fvqa_rmsnorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(rstd), rows, dim, float(eps),
                                       dt_code(x.dtype), _stream())
     _lib.check(rc, "fvqa_rmsnorm_fwd")
     return y
@@ -345,7 +352,7 @@ def rmsnorm_bwd(g, x, w, rstd, dx, resid=None, rows: Optional[int] = None):
     for t in (g, x, dx, resid):
         _need(t is None or (t.shape[-1] == dim and t.numel() >= rows * dim), "rmsnorm_bwd: shape")
     _need(rstd.dtype == torch.float32 and rstd.numel() >= rows and w.numel() == dim, "rmsnorm_bwd: rstd/w")
-    rc = _lib.load().fvqa_rmsnorm_bwd(_ptr(g), _ptr(x), _ptr(w), _ptr(rstd), _ptr(resid), _ptr(dx), rows, dim,
+    rc = _lib.load(g.dtype).fvqa_rmsnorm_bwd(_ptr(g), _ptr(x), _ptr(w), _ptr(rstd), _ptr(resid), _ptr(dx), rows, dim,
                                       dt_code(x.dtype), _stream())
     _lib.check(rc, "fvqa_rmsnorm_bwd")
     return dx
@@ -358,7 +365,7 @@ def rope_qk(qkv, cos_t, sin_t, n_seq: int, seq_len: int, n_heads: int, head_dim:
     _need(cos_t.dtype == sin_t.dtype == torch.float32, "rope_qk: table dtype")
     _need(cos_t.shape[-1] == head_dim // 2 and cos_t.shape[0] >= seq_len and sin_t.shape == cos_t.shape,
           "rope_qk: table shape")
-    rc = _lib.load().fvqa_rope_qk(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), n_seq, seq_len, n_heads, head_dim,
+    rc = _lib.load(qkv.dtype).fvqa_rope_qk(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), n_seq, seq_len, n_heads, head_dim,
                                   int(inverse), dt_code(qkv.dtype), _stream())
     _lib.check(rc, "fvqa_rope_qk")
     return qkv
@@ -368,7 +375,7 @@ def swiglu_fwd(ab, z, rows: int, hidden: int):
     _dev(ab, z)
     _need(ab.dtype == z.dtype, "swiglu_fwd: dtype")
     _need(ab.numel() >= rows * 2 * hidden and z.numel() >= rows * hidden, "swiglu_fwd: shape")
-    rc = _lib.load().fvqa_swiglu_fwd(_ptr(ab), _ptr(z), rows, hidden, dt_code(ab.dtype), _stream())
+    rc = _lib.load(ab.dtype).fvqa_swiglu_fwd(_ptr(ab), _ptr(z), rows, hidden, dt_code(ab.dtype), _stream())
     _lib.check(rc, "fvqa_swiglu_fwd")
     return z
 
@@ -378,7 +385,7 @@ def swiglu_bwd(dz, ab, dab, rows: int, hidden: int):
     _need(dz.dtype == ab.dtype == dab.dtype, "swiglu_bwd: dtype")
     _need(ab.numel() >= rows * 2 * hidden and dab.numel() >= rows * 2 * hidden and dz.numel() >= rows * hidden,
           "swiglu_bwd: shape")
-    rc = _lib.load().fvqa_swiglu_bwd(_ptr(dz), _ptr(ab), _ptr(dab), rows, hidden, dt_code(ab.dtype), _stream())
+    rc = _lib.load(ab.dtype).fvqa_swiglu_bwd(_ptr(dz), _ptr(ab), _ptr(dab), rows, hidden, dt_code(ab.dtype), _stream())
     _lib.check(rc, "fvqa_swiglu_bwd")
     return dab
 
@@ -387,7 +394,7 @@ def cast_rows(src, dst_rows):
     """dst_rows (n, dim) storage dtype <- src (n, dim) fp32."""
     _dev(src, dst_rows)
     _need(src.dtype == torch.float32 and src.shape == dst_rows.shape and src.dim() == 2, "cast_rows: shape")
-    rc = _lib.load().fvqa_cast_rows(_ptr(src), _ptr(dst_rows), src.shape[0], src.shape[1],
+    rc = _lib.load(dst_rows.dtype).fvqa_cast_rows(_ptr(src), _ptr(dst_rows), src.shape[0], src.shape[1],
                                     dt_code(dst_rows.dtype), _stream())
     _lib.check(rc, "fvqa_cast_rows")
     return dst_rows
@@ -405,7 +412,7 @@ def _attn_shapes(qkv, n_seq, S, H, Dh, A):
 def kv_rider_ahead(dtype: torch.dtype) -> bool:
     """True when the step computes the adapter K/V rows of layer i+1 as the rider of layer i's W1|W3 launch (layer 0's as a
     launch of its own before the walk) instead of beside layer i+1's QKV projection (csrc/schedule.hip)."""
-    return bool(_lib.load().fvqa_kv_rider_ahead(dt_code(dtype)))
+    return bool(_lib.load(dtype).fvqa_kv_rider_ahead(dt_code(dtype)))
 
 
 def swiglu_st() -> bool:
@@ -416,14 +423,14 @@ def swiglu_st() -> bool:
 def rope_in_gemm(dtype: torch.dtype) -> bool:
     """True when the step rotates q, k in the QKV projection's epilogue (gemm_nt_rope): the arena's qkv rows hold ROTATED
     q, k, attn_fwd runs without tables and the backward is attn_bwd(..., prerotated=True)."""
-    return bool(_lib.load().fvqa_rope_in_gemm(dt_code(dtype)))
+    return bool(_lib.load(dtype).fvqa_rope_in_gemm(dt_code(dtype)))
 
 
 def gemm_nt_rope(a, b, out, rope, seq_len, head_dim, n_heads, *, rider_a=None, rider_b=None, rider_out=None):
     """out (M, 3*D) = a @ b.T with RoPE applied to the q | k columns [0, 2*D) in the epilogue (bf16; position = row % seq_len);
     optional rider (<= 16 rows) as gemm_nt_rider."""
     _dev(a, b, out, rider_a, rider_b, rider_out, rows_strided=True)
-    _need(a.dtype == b.dtype == out.dtype == torch.bfloat16, "gemm_nt_rope: bf16")
+    _need(a.dtype == b.dtype == out.dtype and a.dtype in (torch.bfloat16, torch.float16), "gemm_nt_rope: 16-bit storage")
     for t in (a, b, out):
         _need(t.dim() == 2 and t.stride(1) == 1, "gemm_nt_rope: 2-D tensors with unit inner stride")
     M, K = a.shape
@@ -443,7 +450,7 @@ def gemm_nt_rope(a, b, out, rope, seq_len, head_dim, n_heads, *, rider_a=None, r
                           rider_b.stride(0), rider_out.stride(0), 0)
     ws = gemm_workspace(a.device)
     import ctypes
-    rc = _lib.load().fvqa_gemm_nt_rope(_ptr(a), _ptr(b), _ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+    rc = _lib.load(a.dtype).fvqa_gemm_nt_rope(_ptr(a), _ptr(b), _ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                                        ctypes.byref(rp), ctypes.byref(rd) if rd is not None else None, _ptr(ws), ws.numel(),
                                        _stream())
     _lib.check(rc, "fvqa_gemm_nt_rope")
@@ -452,7 +459,7 @@ def gemm_nt_rope(a, b, out, rope, seq_len, head_dim, n_heads, *, rider_a=None, r
 
 def attn_rope_fused(dtype: torch.dtype) -> bool:
     """True when attn_fwd / attn_bwd of this dtype rotate q,k themselves (rope=(cos, sin) argument)."""
-    return bool(_lib.load().fvqa_attn_rope_fused(dt_code(dtype)))
+    return bool(_lib.load(dtype).fvqa_attn_rope_fused(dt_code(dtype)))
 
 
 def _rope_tables(rope, S, Dh, what):
@@ -477,7 +484,7 @@ def attn_fwd(qkv, o, lse_a, lse_t, gate1, gate2, vstart, n_seq, S, H, Dh, A, F, 
     for t in (gate1, gate2):
         _need(t.dtype == torch.float32 and t.numel() == H, "attn_fwd: gate shape")
     _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "attn_fwd: vstart")
-    rc = _lib.load().fvqa_attn_fwd(_ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1), _ptr(gate2),
+    rc = _lib.load(qkv.dtype).fvqa_attn_fwd(_ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1), _ptr(gate2),
                                    _ptr(vstart), _ptr(cos_t), _ptr(sin_t), n_seq, S, H, Dh, A, F,
                                    dt_code(qkv.dtype), _stream())
     _lib.check(rc, "fvqa_attn_fwd")
@@ -497,7 +504,7 @@ def attn_decode(qkv_row, qkv_cache, o_row, gate1, gate2, vstart, pos, rope, n_se
     _need(vstart.dtype == torch.int32 and vstart.numel() == n_seq, "attn_decode: vstart")
     for t in (gate1, gate2):
         _need(t.dtype == torch.float32 and t.numel() == H, "attn_decode: gate shape")
-    rc = _lib.load().fvqa_attn_decode(_ptr(qkv_row), _ptr(qkv_cache), _ptr(o_row), _ptr(gate1), _ptr(gate2),
+    rc = _lib.load(qkv_cache.dtype).fvqa_attn_decode(_ptr(qkv_row), _ptr(qkv_cache), _ptr(o_row), _ptr(gate1), _ptr(gate2),
                                       _ptr(vstart), _ptr(pos), _ptr(cos_t), _ptr(sin_t), n_seq, S, H, Dh, A, F,
                                       1 if cache_rotated else 0, dt_code(qkv_row.dtype), _stream())
     _lib.check(rc, "fvqa_attn_decode")
@@ -529,7 +536,7 @@ def attn_bwd(d_o, qkv, o, lse_a, lse_t, gate1, gate2, vstart, dqkv, dgate1, dgat
     wbytes = workspace.numel() * workspace.element_size()
     _need(wbytes >= attn_bwd_workspace(n_seq, S, H, Dh, A), "attn_bwd: workspace too small")
     # prerotated: q, k in `qkv` were rotated by gemm_nt_rope; dqkv still receives the gradients of the raw projections
-    fn = _lib.load().fvqa_attn_bwd_rotated if prerotated else _lib.load().fvqa_attn_bwd
+    fn = _lib.load(qkv.dtype).fvqa_attn_bwd_rotated if prerotated else _lib.load(qkv.dtype).fvqa_attn_bwd
     _need(not prerotated or cos_t is not None, "attn_bwd: prerotated needs the rope tables")
     rc = fn(_ptr(d_o), _ptr(qkv), _ptr(o), _ptr(lse_a), _ptr(lse_t), _ptr(gate1), _ptr(gate2), _ptr(vstart), _ptr(cos_t),
             _ptr(sin_t), _ptr(dqkv), _ptr(dgate1), _ptr(dgate2), _ptr(workspace), wbytes, n_seq, S, H, Dh, A, F,
@@ -547,7 +554,7 @@ def visual_proj_fwd(video, W, temporal, vf_raw, vf_tok):
     _need(video.dtype == W.dtype == temporal.dtype == vf_raw.dtype == torch.float32, "visual_proj_fwd: fp32")
     _need(W.shape[1] == K and temporal.shape[1] == D and R % F == 0, "visual_proj_fwd: shapes")
     _need(tuple(vf_raw.shape) == (R, D) and tuple(vf_tok.shape) == (R, D), "visual_proj_fwd: out shapes")
-    rc = _lib.load().fvqa_visual_proj_fwd(_ptr(video), _ptr(W), _ptr(temporal), _ptr(vf_raw), _ptr(vf_tok), R, F,
+    rc = _lib.load(vf_tok.dtype).fvqa_visual_proj_fwd(_ptr(video), _ptr(W), _ptr(temporal), _ptr(vf_raw), _ptr(vf_tok), R, F,
                                           K, D, dt_code(vf_tok.dtype), _stream())
     _lib.check(rc, "fvqa_visual_proj_fwd")
 
@@ -576,7 +583,7 @@ def embed_splice(ids, emb, vf_tok, h, n_seq, S, F, *, vstart: int = 0, zero_labe
           "embed_splice: zero_labels")
     _need(index is None or (index.dtype == torch.int64 and index.numel() == n_seq * F), "embed_splice: index")
     # ids must address the table: checked on the host copy by the caller (see model.py)
-    rc = _lib.load().fvqa_embed_splice(_ptr(ids), _ptr(emb), _ptr(vf_tok), _ptr(zero_labels), _ptr(index), _ptr(h),
+    rc = _lib.load(emb.dtype).fvqa_embed_splice(_ptr(ids), _ptr(emb), _ptr(vf_tok), _ptr(zero_labels), _ptr(index), _ptr(h),
                                        n_seq, S, D, F, vstart, mode, dt_code(h.dtype), _stream())
     _lib.check(rc, "fvqa_embed_splice")
     return h
@@ -588,7 +595,7 @@ def splice_bwd(dh, d_tok, n_seq, S, F, *, vstart: int = 0, index=None, mode: int
     _need(dh.numel() >= n_seq * S * D, "splice_bwd: dh")
     _need(d_tok.dtype == torch.float32 and d_tok.numel() == n_seq * F * D, "splice_bwd: d_tok")
     _need(index is None or (index.dtype == torch.int64 and index.numel() == n_seq * F), "splice_bwd: index")
-    rc = _lib.load().fvqa_splice_bwd(_ptr(dh), _ptr(index), _ptr(d_tok), n_seq, S, D, F, vstart, mode,
+    rc = _lib.load(dh.dtype).fvqa_splice_bwd(_ptr(dh), _ptr(index), _ptr(d_tok), n_seq, S, D, F, vstart, mode,
                                      dt_code(dh.dtype), _stream())
     _lib.check(rc, "fvqa_splice_bwd")
 
@@ -611,7 +618,7 @@ def ce_bwd(logits, labels, lse, loss_sum, gscale, dlogits, n_seq, S, V, ignore_i
     _need(dlogits.numel() == n_seq * S * V, "ce_bwd: dlogits")
     _need(labels.dtype == torch.int64 and labels.numel() == n_seq * S, "ce_bwd: labels")
     _need(gscale.dtype == torch.float32 and gscale.numel() >= 1 and loss_sum.numel() >= 2, "ce_bwd: scalars")
-    rc = _lib.load().fvqa_ce_bwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss_sum), _ptr(gscale), _ptr(dlogits),
+    rc = _lib.load(dlogits.dtype).fvqa_ce_bwd(_ptr(logits), _ptr(labels), _ptr(lse), _ptr(loss_sum), _ptr(gscale), _ptr(dlogits),
                                  n_seq, S, V, ignore_index, dt_code(dlogits.dtype), _stream())
     _lib.check(rc, "fvqa_ce_bwd")
 
@@ -623,7 +630,7 @@ def qav_head_fwd(xn, vf_raw, labels, probs, rowloss, loss_sum, n_seq, S, D, F, t
     _need(labels.dtype == torch.int64 and labels.numel() == n_seq * S, "qav_head_fwd: labels")
     _need(probs.dtype == torch.float32 and probs.numel() >= n_seq * S * F, "qav_head_fwd: probs")
     _need(rowloss.dtype == torch.float32 and rowloss.numel() >= n_seq * S, "qav_head_fwd: rowloss")
-    rc = _lib.load().fvqa_qav_head_fwd(_ptr(xn), _ptr(vf_raw), _ptr(labels), _ptr(probs), _ptr(rowloss),
+    rc = _lib.load(xn.dtype).fvqa_qav_head_fwd(_ptr(xn), _ptr(vf_raw), _ptr(labels), _ptr(probs), _ptr(rowloss),
                                        _ptr(loss_sum), n_seq, S, D, F, float(tau), dt_code(xn.dtype), _stream())
     _lib.check(rc, "fvqa_qav_head_fwd")
 
@@ -634,7 +641,7 @@ def qav_head_bwd(xn, vf_raw, labels, probs, loss_sum, gscale, dxn, d_raw, n_seq,
     _need(vf_raw.numel() == n_seq * F * D and d_raw.dtype == torch.float32 and d_raw.numel() == n_seq * F * D,
           "qav_head_bwd: vf")
     _need(labels.dtype == torch.int64 and labels.numel() == n_seq * S, "qav_head_bwd: labels")
-    rc = _lib.load().fvqa_qav_head_bwd(_ptr(xn), _ptr(vf_raw), _ptr(labels), _ptr(probs), _ptr(loss_sum),
+    rc = _lib.load(xn.dtype).fvqa_qav_head_bwd(_ptr(xn), _ptr(vf_raw), _ptr(labels), _ptr(probs), _ptr(loss_sum),
                                        _ptr(gscale), _ptr(dxn), _ptr(d_raw), n_seq, S, D, F, float(tau),
                                        dt_code(xn.dtype), _stream())
     _lib.check(rc, "fvqa_qav_head_bwd")

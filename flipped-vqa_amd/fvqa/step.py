@@ -143,8 +143,8 @@ class StepEngine:
         if self.device.type != "cuda":
             raise RuntimeError("Flipped-VQA hot path runs only on a ROCm device (no CPU fallback); "
                                "move the model with model.to('cuda') first")
-        if self.dtype not in (torch.float32, torch.bfloat16):
-            raise TypeError(f"frozen weights must be float32 or bfloat16, got {self.dtype}")
+        if self.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise TypeError(f"frozen weights must be float32, bfloat16 or float16, got {self.dtype}")
         self.pack = FrozenPack(model, self.layer_ids)
         cos, sin = model.rope_tables()
         self.cos = cos.to(self.device).contiguous()
@@ -190,7 +190,7 @@ class StepEngine:
         plan.dcur, plan.dnxt, plan.d_o = ar.da.data_ptr(), ar.db.data_ptr(), ar.do.data_ptr()
         plan.cos_t, plan.sin_t, plan.vstart = self.cos.data_ptr(), self.sin.data_ptr(), vstart.data_ptr()
         plan.attn_ws_bytes = ar.attn_ws.numel()
-        lib = _lib.load()
+        lib = _lib.load(self.dtype)
         need = int(lib.fvqa_layers_gemm_workspace(C.addressof(plan)))
         # the stream's one GEMM workspace (ops.gemm_workspace): every launch of the step, from either schedule, shares
         # its flags, slabs and ERROR word, which the loss scaler hands to the unscale kernel
@@ -280,7 +280,7 @@ class StepEngine:
 
         if self.use_native_schedule():
             plan = self.layer_plan(ar, m._flat, vstart)
-            _lib.check(_lib.load().fvqa_layers_fwd(C.addressof(plan), torch.cuda.current_stream().cuda_stream),
+            _lib.check(_lib.load(self.dtype).fvqa_layers_fwd(C.addressof(plan), torch.cuda.current_stream().cuda_stream),
                        "fvqa_layers_fwd")
         else:
             self._layers_fwd_py(ar, vstart, n_seq, S)
@@ -373,7 +373,7 @@ class StepEngine:
         if self.use_native_schedule():
             plan = self.layer_plan(ar, grads, sv["vstart"])
             out = C.c_void_p()
-            _lib.check(_lib.load().fvqa_layers_bwd(C.addressof(plan), ar.dxnf.data_ptr(), C.addressof(out),
+            _lib.check(_lib.load(self.dtype).fvqa_layers_bwd(C.addressof(plan), ar.dxnf.data_ptr(), C.addressof(out),
                                                    torch.cuda.current_stream().cuda_stream), "fvqa_layers_bwd")
             cur = ar.da if out.value == ar.da.data_ptr() else ar.db
         else:

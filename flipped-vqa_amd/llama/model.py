@@ -172,11 +172,8 @@ class Transformer(nn.Module):
         w = self.tok_embeddings.weight
         key = (w.data_ptr(), w.dtype, str(w.device), self.adapter_query.weight.data_ptr())
         if self._engine is None or self._engine_key is None or key[:3] != self._engine_key[:3]:
-            if w.dtype == torch.float16:
-                # the reference keeps frozen weights in fp16; gfx950 kernels store bf16
-                for n, p in self.named_parameters():
-                    if p.dtype == torch.float16:
-                        p.data = p.data.to(torch.bfloat16)
+            # fp16 frozen weights — the reference's own storage type (llama_vqa.py:63) — stay fp16: the fp16 build of the kernels
+            # (libfvqa_hip_f16.so, v_mfma_f32_16x16x32_f16) takes them as they are. (Rounds 2-4 re-rounded them to bf16 here.)
             self._flat = FlatParams(self)
             self._engine = StepEngine(self)
             w = self.tok_embeddings.weight

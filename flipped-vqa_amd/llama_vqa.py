@@ -45,8 +45,8 @@ def merge_shards(shards, n_layers):
 
 def _storage_dtype(args):
     name = str(getattr(args, "dtype", "bf16")).lower()
-    # "fp16": the reference's own storage type (llama_vqa.py:63 builds under HalfTensor); the module then holds the shards'
-    # fp16 values exactly and the step engine converts them to bf16 when it packs the weights (llama/model.py ensure_engine)
+    # "fp16": the reference's own storage type (llama_vqa.py:63 builds under HalfTensor); the module holds the shards' fp16 values
+    # exactly and the fp16 build of the kernels (libfvqa_hip_f16.so) computes on them as they are
     return {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
             "fp16": torch.float16, "float16": torch.float16}[name]
 

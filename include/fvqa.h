@@ -15,6 +15,8 @@
  *   - `dtype` selects the storage type of activations / frozen weights:
  *       FVQA_F32  — exact-fp32 validation build of every kernel (fp32-in MFMA),
  *       FVQA_BF16 — production build (bf16 storage, fp32 accumulate);
+ *       FVQA_F16  — the same with IEEE fp16 storage (libfvqa_hip_f16.so; wherever an entry below says "bf16" / FVQA_BF16 for
+ *                   the 16-bit build, that library reads it as fp16 / FVQA_F16);
  *     trainable parameters, their gradients, softmax statistics and losses are always fp32;
  *   - matrices are row-major; `rows` = sequences*seq_len flattened (n*S + s);
  *   - return value: 0 (FVQA_OK) or a negative FVQA_E* code / -(1000+hipError_t).
@@ -30,6 +32,10 @@ extern "C" {
 
 #define FVQA_F32 0
 #define FVQA_BF16 1
+#define FVQA_F16 2 /* IEEE fp16 storage — the reference's own (llama_vqa.py:63 builds the model under torch.cuda.HalfTensor). Served by
+                      libfvqa_hip_f16.so: the same sources compiled with the 16-bit storage type switched (csrc/common.h), same
+                      entry points; libfvqa_hip.so serves FVQA_BF16. Each library rejects the other's 16-bit code (FVQA_EINVAL),
+                      both serve FVQA_F32. The host (fvqa/_lib.py) binds the library of the model's storage dtype. */
 
 #define FVQA_OK 0
 #define FVQA_EINVAL (-1) /* null pointer / bad enum            */

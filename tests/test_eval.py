@@ -28,7 +28,7 @@ def golden_batch(GOLD=GOLD):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("pname", ["tiny", "7b_l2", "tiny_peaked", "7b_l2_peaked", "tiny_peakedperm", "7b_l2_peakedperm"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_generation_matches_reference(dtype, pname):
     """fp32 build: the 31 greedy tokens per sample, the chosen option and the similarities equal the reference's
     (argmax over fp32 logits that agree to ~1e-6) — at tiny width and at 7B width (32 heads, D = 4096, two layers).

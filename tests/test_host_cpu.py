@@ -1,4 +1,5 @@
 """Host-side logic and the C-ABI surface, no GPU needed."""
+import ctypes as C
 import math
 import os
 import re
@@ -29,13 +30,24 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.fvqa_arch() == b"gfx950"
     # argument validation happens before any launch: callable without a GPU
     assert lib.fvqa_gemm_nt(None, None, None, None, None, 1, 1, 64, 64, 64, 1, 1, 1, 1, 0, 0, None, 0, None) == -1
+    # the fp16-storage build of the same sources (libfvqa_hip_f16.so): same ABI, same symbols, same source hash; each library
+    # serves its own 16-bit dtype code and refuses the other's before anything is launched
+    lib16 = _lib.load("f16")
+    assert lib16 is not lib and _lib.load(_lib.F16) is lib16 and _lib.load(_lib.BF16) is lib and _lib.load(_lib.F32) is lib
+    assert lib16.fvqa_version() == _lib.ABI_VERSION and lib16.fvqa_source_hash() == lib.fvqa_source_hash()
+    assert lib.fvqa_attn_rope_fused(_lib.BF16) == 1 and lib.fvqa_attn_rope_fused(_lib.F16) == 0
+    assert lib16.fvqa_attn_rope_fused(_lib.F16) == 1 and lib16.fvqa_attn_rope_fused(_lib.BF16) == 0
+    one = C.c_void_p(256)                               # (a non-null pointer: the dtype check comes first, nothing is read)
+    for L_, ok, bad in ((lib, _lib.BF16, _lib.F16), (lib16, _lib.F16, _lib.BF16)):
+        assert L_.fvqa_rmsnorm_fwd(one, one, one, None, 1, 7, 1e-6, bad, None) == -1        # FVQA_EINVAL: not this build's type
+        assert L_.fvqa_rmsnorm_fwd(one, one, one, None, 1, 7, 1e-6, ok, None) == -2         # FVQA_ESHAPE: type accepted, dim % 8
     assert lib.fvqa_attn_bwd_workspace(2, 128, 32, 128, 10) > 0
     assert lib.fvqa_attn_bwd_workspace(2, 128, 32, 64, 10) == 0      # head_dim != 128 unsupported
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setenv("FVQA_LIB", str(tmp_path / "nope.so"))
-    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "_LIBS", {})
     with pytest.raises(_lib.FvqaLibraryError):
         _lib.load()
 
@@ -308,7 +320,7 @@ def test_stale_library_is_refused(monkeypatch):
     from fvqa import _lib, build
     lib = _lib.load()                                     # the in-tree build matches its sources
     assert lib.fvqa_source_hash().decode() == build.source_hash()
-    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "_LIBS", {})
     monkeypatch.setattr(build, "source_hash", lambda: "0" * 64)      # = a kernel source touched after the build
     with pytest.raises(_lib.FvqaLibraryError, match="stale binary"):
         _lib.load()

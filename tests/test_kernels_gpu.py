@@ -1,6 +1,7 @@
 """Per-kernel parity: every C-ABI entry of libfvqa_hip.so against the oracle primitive
 (oracle/ref_cpu.py, fp64 on CPU) on seeded inputs. fp32 build: tolerance 2e-5 of the output's
-max magnitude (GEMM K<=4096: 5e-5); bf16 build: 2e-2 (8-bit mantissa storage). Run with -m gpu."""
+max magnitude (GEMM K<=4096: 5e-5); bf16 build: 2e-2 (8-bit mantissa storage); the fp16 build
+(libfvqa_hip_f16.so: 11-bit mantissa) is held to the bf16 bounds. Run with -m gpu."""
 import math
 
 import pytest
@@ -12,7 +13,7 @@ from fvqa import ops  # noqa: E402
 from oracle import ref_cpu  # noqa: E402
 
 DEV = "cuda"
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]     # fp16: libfvqa_hip_f16.so, the same kernels on IEEE fp16 storage
 
 
 def tol(dtype, f32=2e-5, bf16=2e-2):

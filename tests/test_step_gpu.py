@@ -90,6 +90,35 @@ def test_bf16_step_against_reference_golden(case):
     _free(model)
 
 
+FP16_CASES = ["tiny_all", "small_all", "7b_l2_b8_vqa_peaked", "7b_l2_b8_all_peaked", "7b_l2_s650_all_peaked", "13b_l2_all_peaked",
+              "7b_full_b8_vqa_peaked", "7b_l16_b8_all_peaked"]
+FP16_LOSS_SCALE = 1024.0      # the reference trains fp16 under a GradScaler (util/misc.py:253-273); unscaled, fp16 gradients underflow
+
+
+@pytest.mark.parametrize("case", FP16_CASES)
+def test_fp16_step_against_reference_golden(case):
+    """The fp16-storage build (libfvqa_hip_f16.so: the same kernels with IEEE fp16 as the 16-bit type, v_mfma_f32_16x16x32_f16;
+    the reference's own storage type, llama_vqa.py:63) against the reference's goldens, at the bf16 build's bounds (fp16 keeps
+    three more mantissa bits, so it sits well inside them): losses, sampled logits, layer outputs, every trainable's gradient,
+    token argmax on every decided row. The backward runs under a loss scale, as the reference's does (GradScaler), and the
+    gradients are unscaled before the comparison."""
+    pname, over = CASES[case]
+    cfg = synth.preset(pname, **over)
+    model, _ = build_model(cfg, torch.float16)
+    batch = synth.make_batch(cfg, seed=0)
+    w = FP16_LOSS_SCALE
+    losses, grads, logits, layer_out = run_step(model, batch, loss_weights=(w, w, w))
+    grads = {n: g / w for n, g in grads.items()}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=BF16_LOSS_RTOL, tol=BF16_TOL,
+                              min_decided=BF16_MIN_DECIDED.get(case, 0.4))
+    print(case, "fp16", {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
+    model._engine.check_gemm_error()
+    from fvqa import _lib
+    assert "f16" in _lib._LIBS                               # served by the fp16 library, not by a conversion
+    _free(model)
+
+
 def _oracle(cfg, sd, batch, weights=(1.0, 1.0, 1.0)):
     m = ref_cpu.RefModel(cfg, sd, dtype=torch.float64)
     return m.step(batch, loss_weights=weights, keep=True)

@@ -269,7 +269,12 @@ def gen(NBT, sk=False):
         e("L_nostamp1_%=:")
         L.extend(gen_sk_tail())
 
-    body = "\n".join(f'      "{ln}\\n"' for ln in L)
+    def cline(ln):
+        # the MFMA mnemonic is a macro of common.h (bf16 in libfvqa_hip.so, fp16 in libfvqa_hip_f16.so): adjacent string literals
+        if ln.startswith("v_mfma_f32_16x16x32_bf16 "):
+            return f'      FVQA_MFMA_H16_ASM "{ln[len("v_mfma_f32_16x16x32_bf16"):]}\\n"'
+        return f'      "{ln}\\n"'
+    body = "\n".join(cline(ln) for ln in L)
     accs = ", ".join(f'"+{{a[{16 * j}:{16 * j + 15}]}}"(acc[{j}])' for j in range(NBT))
     clob = ['"memory"', '"scc"', '"vcc"']
     clob += [f'"v{n}"' for n in range(64, 248)]

@@ -93,14 +93,17 @@ def test_bf16_step_against_reference_golden(case):
 FP16_CASES = ["tiny_all", "small_all", "7b_l2_b8_vqa_peaked", "7b_l2_b8_all_peaked", "7b_l2_s650_all_peaked", "13b_l2_all_peaked",
               "7b_full_b8_vqa_peaked", "7b_l16_b8_all_peaked"]
 FP16_LOSS_SCALE = 1024.0      # the reference trains fp16 under a GradScaler (util/misc.py:253-273); unscaled, fp16 gradients underflow
+# measured against the reference's goldens (gpurun_out/r05, round 5): losses <= 5.1e-5, sampled logits <= 4.3e-4 of the logit range,
+# layer outputs <= 9.1e-3, gradients <= 1.6e-3 — the fp16 build meets north_star's 1e-3 on loss and logits at full depth
+FP16_TOL = dict(loss=5e-4, logits=2e-3, layer=3e-2, grad=1e-2)
 
 
 @pytest.mark.parametrize("case", FP16_CASES)
 def test_fp16_step_against_reference_golden(case):
     """The fp16-storage build (libfvqa_hip_f16.so: the same kernels with IEEE fp16 as the 16-bit type, v_mfma_f32_16x16x32_f16;
-    the reference's own storage type, llama_vqa.py:63) against the reference's goldens, at the bf16 build's bounds (fp16 keeps
-    three more mantissa bits, so it sits well inside them): losses, sampled logits, layer outputs, every trainable's gradient,
-    token argmax on every decided row. The backward runs under a loss scale, as the reference's does (GradScaler), and the
+    the reference's own storage type, llama_vqa.py:63) against the reference's goldens, at its own bounds (FP16_TOL: fp16 keeps
+    three more mantissa bits than bf16 and lands an order of magnitude closer to the fp32 reference): losses within 5e-4, sampled
+    logits within 2e-3 of the range, every trainable's gradient within 1e-2, token argmax equal on every decided row (>= 95 % of the rows on the peaked fixtures, >= 70 % on the random-head ones; measured 100 % / 90-98 %). The backward runs under a loss scale, as the reference's does (GradScaler), and the
     gradients are unscaled before the comparison."""
     pname, over = CASES[case]
     cfg = synth.preset(pname, **over)
@@ -110,8 +113,8 @@ def test_fp16_step_against_reference_golden(case):
     losses, grads, logits, layer_out = run_step(model, batch, loss_weights=(w, w, w))
     grads = {n: g / w for n, g in grads.items()}
     assert all(torch.isfinite(g).all() for g in grads.values())
-    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=BF16_LOSS_RTOL, tol=BF16_TOL,
-                              min_decided=BF16_MIN_DECIDED.get(case, 0.4))
+    rep = compare_with_golden(load_golden(case), losses, grads, logits, layer_out, rtol=BF16_LOSS_RTOL, tol=FP16_TOL,
+                              min_decided=0.95 if case.endswith("_peaked") else 0.7)     # measured: 100 % / 90-98 %
     print(case, "fp16", {k: f"{v:.2e}" if isinstance(v, float) else v for k, v in rep.items()})
     model._engine.check_gemm_error()
     from fvqa import _lib

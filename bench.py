@@ -580,7 +580,7 @@ def main():
             # fabric-side bytes per launch from the rocprofv3 --pmc passes of THIS command (tools/pmc_summary.py:
             # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), valid only for the kernel sources they were collected with
             traffic, tsrc = None, None
-            tj = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_mfma_lds.json", "r03_pmc_mfma_lds.json"))
+            tj = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_mfma_lds.json", "r04_pmc_mfma_lds.json", "r03_pmc_mfma_lds.json"))
                        if os.path.exists(f)), None)
             if a.dtype == "bf16" and a.model == "7B" and not (a.vaq or a.qav) and a.seq_len == 128 and tj:
                 pm = json.load(open(tj))

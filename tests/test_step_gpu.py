@@ -61,7 +61,11 @@ def test_fp32_step_matches_reference_golden(case):
 # margins of a few per cent of the logit range: the floors below are 0.8 x the fractions measured in round 2
 # (profiles/r02_parity_vs_golden.log: 94/189 ... 700/1016; the full-depth case 64/254), so the check cannot silently
 # decay to "no row decided".
-BF16_MIN_DECIDED = {"small_all": 0.40, "7b_l2_all": 0.49, "7b_full_all": 0.20, "7b_l2_b8_vqa": 0.55, "7b_l2_b8_all": 0.48,
+# Round 5: the full-depth random-head floor re-based. The decided fraction is a steep function of the LARGEST of 256 sampled
+# logit errors (band = 8 x it): final sources 69 / 254 and 72 / 254 rows (errors 8.6e-3 / 6.9e-3 of the logit range); a round-4
+# scratch build whose RMSNorm differed in the last fp32 bit (other FMA contraction) read 9.2e-3 -> 0.177 and failed the old 0.20.
+# 0.12 = the fraction decided at an error of 1.1e-2 (the logits' own bound is 2e-2).
+BF16_MIN_DECIDED = {"small_all": 0.40, "7b_l2_all": 0.49, "7b_full_all": 0.12, "7b_l2_b8_vqa": 0.55, "7b_l2_b8_all": 0.48,
                     "7b_l2_s650_all": 0.47, "13b_l2_all": 0.49,
                     "7b_l2_b8_vqa_peaked": 0.95, "7b_l2_b8_all_peaked": 0.95, "7b_full_all_peaked": 0.95,
                     "7b_l2_s650_all_peaked": 0.95, "13b_l2_all_peaked": 0.95,

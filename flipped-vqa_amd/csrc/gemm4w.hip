@@ -29,11 +29,13 @@ int launch4(const G4Args& a, hipStream_t st) {
   auto k = gemm4w_k<NBT, TO, EPI>;
   static std::atomic<unsigned long long> attr_done{0};          // one bit per device (fvqa_attr_needed)
   if (fvqa_attr_needed(attr_done)) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<NBT>::RING_BYTES);
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
+  // dynamic LDS: the rings of the main loop; a launch that carries a rider asks for the rider's DMA ring + partial blocks if larger
+  const int lds = a.rider.on && a.rider.dma && Geo<NBT>::RING_BYTES < FVQA_SKINNY_DMA_LDS ? FVQA_SKINNY_DMA_LDS : Geo<NBT>::RING_BYTES;
   {
     FvqaProbeScope ts(st, 2.0 * a.M * a.N * a.K, EPI | (sizeof(TO) == 4 ? 32 : 0) | 128);       // kind bit 7: the 4-wave kernel
-    hipLaunchKernelGGL(k, dim3(a.grid), dim3(256), Geo<NBT>::RING_BYTES, st, a);
+    hipLaunchKernelGGL(k, dim3(a.grid), dim3(256), lds, st, a);
   }
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
@@ -63,6 +65,12 @@ int dispatch4(const G4Args& a, int out_dtype, int epilogue, hipStream_t st) {
 // tile time with 192 busy, 0.82 with 172); an epilogue term per round; a rider streams its weight rows in whole passes of 32
 // columns at ~17.5 GB/s per light workgroup from the start of the last round (re-fitted in round 5 against the width survey
 // of tools/gemm4w_widths.py) and is a launch of its own (~3.2 TB/s + 10 us) when fewer than 8 workgroups are light.
+// FVQA_RIDER_DMA=0 keeps the register form of the rider's strips (A/B runs); read once
+static bool fvqa_rider_dma_enabled() {
+  static const bool on = !(getenv("FVQA_RIDER_DMA") && getenv("FVQA_RIDER_DMA")[0] == '0');
+  return on;
+}
+
 static double g4_cost_us(int M, int N, int K, int nbt, int epilogue, int out_dtype, const fvqa_sk_rider* rider, int n_cu,
                          int* light_out) {
   const int tm = (M + 255) / 256, tn = (N + 16 * nbt - 1) / (16 * nbt);
@@ -71,7 +79,9 @@ static double g4_cost_us(int M, int N, int K, int nbt, int epilogue, int out_dty
   const int last = tiles - (rounds - 1) * n_cu;
   const int light = n_cu - last;
   const double t256 = 101.0 * K / 4096.0;
-  const double eff = nbt == 11 ? 1.04 : 1.0;
+  // 11-block tiles cost 4 % more per column than the wider ones — and a quarter more in a multi-round SwiGLU' launch (measured,
+  // profiles/r05_gemm4w_widths.log: 3072 x 11008: 331.9 us against 262.3 at 12 blocks where this model said 250 against 254)
+  const double eff = nbt == 11 ? (epilogue == FVQA_EPI_SWIGLU_BWD_ST && rounds > 1 ? 1.25 : 1.04) : 1.0;
   double epi = out_dtype == FVQA_F32 ? 4.0 : 4.0;
   if (epilogue == FVQA_EPI_ROPE || epilogue == FVQA_EPI_RESIDUAL) epi = 9.0;
   if (epilogue == FVQA_EPI_SWIGLU_FWD_ST) epi = 7.0;
@@ -86,9 +96,15 @@ static double g4_cost_us(int M, int N, int K, int nbt, int epilogue, int out_dty
       // survey (profiles/r05_gemm4w_widths.log) — S = 384: 35 light workgroups x 4 passes of 512 KiB finished 120 us after the
       // first round, 30 us behind the tiles (the round-4 figure, 23 GB/s without the pass quantum, had it level with them and
       // picked that width: 11.5 % slower than the best one)
+      // ... and with the operands streamed by LDS-DMA (gemm_skinny.h skinny_strip2_dma_4w: K ranges of whole 64-element stages)
+      // ~49 GB/s after ~3.2 us of pipeline fill and partial-block sum per pass (fitted to two rider-bound launches of the width
+      // survey: 24 light workgroups x 6 passes of 512 KiB end with the 232 tiles of dH W2^T at 12 column blocks, 84.6 us against
+      // 82.7 without a rider — the register form needed 139.5; 24 x 14 passes of 320 KiB at 13B take 141 us)
       const int pairs = (rider->N + 31) / 32;
       const int passes = (pairs + light - 1) / light;
-      const double t_r = head + passes * (2.0 * 32 * (double)rider->K) / 17.5e3 + 3.0;
+      const double pass_bytes = 2.0 * 32 * (double)rider->K;
+      const bool dma = fvqa_rider_dma_enabled() && ((rider->K / 8) % 64) == 0;
+      const double t_r = head + passes * (dma ? 3.2 + pass_bytes / 49.0e3 : pass_bytes / 17.5e3) + 3.0;
       const double main_us = total;
       if (t_r > total) total = t_r;
       total += 0.01 * main_us;                        // between rider-bound widths, the one whose tiles finish earlier
@@ -146,7 +162,7 @@ int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void*
   a.tm = (M + 255) / 256;
   a.tn = (N + 16 * nbt - 1) / (16 * nbt);
   a.tiles = a.tm * a.tn;
-  a.rider = G4Rider{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0};
+  a.rider = G4Rider{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   a.rope_cos = rope ? rope->cos_t : nullptr; a.rope_sin = rope ? rope->sin_t : nullptr;
   a.rope_S = rope ? rope->seq_len : 1; a.rope_cols = rope ? rope->cols : 0; a.rope_hp = rope ? rope->head_dim / 2 : 1;
   a.rope_hmask = (rope && (rope->head_dim & (rope->head_dim - 1)) == 0) ? rope->head_dim - 1 : 0;
@@ -165,7 +181,7 @@ int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void*
     const int light = a.grid - (a.tiles - (a.rounds - 1) * a.grid);
     if (light >= 8) {
       a.rider = G4Rider{rider->A, rider->B, rider->C, rider->M, rider->N, rider->K, rider->lda, rider->ldb, rider->ldc,
-                        rider->accumulate_f32, 1};
+                        rider->accumulate_f32, 1, fvqa_rider_dma_enabled() ? 1 : 0};
       if (rode) *rode = 1;
     } else {
       a.grid = a.tiles < n_cu ? a.tiles : n_cu;

@@ -11,6 +11,7 @@ struct G4Rider {
   int M, N, K, lda, ldb, ldc;
   int acc;               // 0: C (bf16) = product; 1: C (fp32) += product
   int on;                // 1: run it on the light workgroups of this launch
+  int dma;               // 1: stream the weight rows by LDS-DMA (FVQA_RIDER_DMA=0 keeps the register form: A/B runs)
 };
 
 struct G4Args {
@@ -285,8 +286,19 @@ __global__ __launch_bounds__(256) void gemm4w_k(const G4Args a) {
     if (pos >= krem) {
       const G4Rider& rd = a.rider;
       float(*part)[8][16][20] = reinterpret_cast<float(*)[8][16][20]>(smem);
+      // operand rows streamed by LDS-DMA through the idle ring memory (gemm_skinny.h: the launch asks for FVQA_SKINNY_DMA_LDS
+      // bytes when it carries a rider) when every K range is whole 64-element stages; same results either way
+      const bool dma = rd.dma && ((rd.K / 8) % 64) == 0;
+      char* ring = smem;
       for (int pair = pos - krem; pair * 32 < rd.N; pair += light) {     // two adjacent 16-column strips per pass
-        if (rd.acc)
+        if (dma) {
+          if (rd.acc)
+            skinny_strip2_dma_4w<float, FVQA_EPI_SKINNY_ACC>((const bf16_t*)rd.A, (const bf16_t*)rd.B, (float*)rd.C, rd.M, rd.N,
+                                                             rd.K, rd.lda, rd.ldb, rd.ldc, pair * 32, ring);
+          else
+            skinny_strip2_dma_4w<bf16_t, FVQA_EPI_NONE>((const bf16_t*)rd.A, (const bf16_t*)rd.B, (bf16_t*)rd.C, rd.M, rd.N, rd.K,
+                                                        rd.lda, rd.ldb, rd.ldc, pair * 32, ring);
+        } else if (rd.acc)
           skinny_strip2_4w<float, FVQA_EPI_SKINNY_ACC>((const bf16_t*)rd.A, (const bf16_t*)rd.B, (float*)rd.C, rd.M, rd.N, rd.K,
                                                        rd.lda, rd.ldb, rd.ldc, pair * 32, part);
         else

@@ -139,3 +139,139 @@ __device__ __forceinline__ void skinny_strip2_4w(const bf16_t* __restrict__ A, c
     }
   }
 }
+
+// ---- the same two strips with the operands streamed by LDS-DMA (round 5) ------------------------------------------------------------
+// skinny_strip2_4w keeps its weight fragments in flight in registers — and hipcc drains the queue (`s_waitcnt vmcnt(0)`) inside
+// its double-buffered loop, so a light workgroup streams ~17.5 GB/s beside the busy CUs of a projection launch: the adapter K/V
+// rider held the W1|W3 launch 18 us past its tiles (1.28 MB per light workgroup in the 75 us its second round lasts) and forced
+// the dH W2^T launch onto 13-block tiles (tools/gemm4w_widths.py with GW_NO_RIDER=1: 149.8 against 167.7 us, 82.0 against 91.6).
+// Here every wave streams the rows of ITS two K ranges — weights AND the <= 16 activation rows — through a private ring in the
+// (idle) LDS of the workgroup: per stage (2 strips + 1 activation block) x 2 ranges x 16 rows x 128 B = 12 KiB as twelve 1-KiB
+// LDS-DMA pieces (8 rows x 128 B = whole cache lines per row; lane-linear image, chunk c of row r at c ^ (r & 7): conflict-free
+// ds_read_b128 fragments, as the GEMM rings), FVQA_SKINNY_DMA_STAGES stages deep: two stages (24 KiB per wave, 96 KiB per
+// workgroup) in flight while one is consumed, no barrier inside the K loop (a wave reads only what it loaded itself; its own
+// counted vmcnt covers its pieces). No load of the loop has a register destination: every vector-memory operation is an LDS-DMA
+// builtin, counted by hand, and there is nothing for the compiler to copy, spill or drain (a first form with inline-asm
+// activation loads let hipcc move their destination registers while the loads were in flight: garbage on three waves of four).
+// ARITHMETIC: unchanged — (strip, K range) chains accumulated in k order, the eight ranges summed in range order: bit for bit the
+// results of skinny_strip2_4w and of the stand-alone skinny_strip. Needs (K / 8) % 64 == 0 (the caller falls back otherwise).
+// LDS: 4 waves x 3 stages x 12 KiB = 144 KiB; the eight partial blocks (`part`, 20 KiB) alias the ring once every wave is done
+// with it (one barrier).
+constexpr int FVQA_SKINNY_DMA_STAGES = 3;
+constexpr int FVQA_SKINNY_DMA_WSTAGE = 12 * 1024;                                        // bytes per wave per stage
+constexpr int FVQA_SKINNY_DMA_LDS = 4 * FVQA_SKINNY_DMA_STAGES * FVQA_SKINNY_DMA_WSTAGE; // 144 KiB per workgroup
+static_assert(FVQA_SKINNY_DMA_LDS >= FVQA_SKINNY2_LDS, "the partial blocks alias the ring");
+
+#ifndef FVQA_SKINNY_DMA_AUX
+#define FVQA_SKINNY_DMA_AUX 0
+#endif
+
+template <typename TO, int EPI>
+__device__ __forceinline__ void skinny_strip2_dma_4w(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                     TO* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int n0,
+                                                     char* ring) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  constexpr int S = FVQA_SKINNY_DMA_STAGES, GROUP = 12;      // LDS-DMA pieces per stage and wave
+  float(*part)[8][16][20] = reinterpret_cast<float(*)[8][16][20]>(ring);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int kw = K / 8;
+  const int nst = kw / 64;                                   // stages: 64 k elements (two k-steps) of each of this wave's ranges
+  const int om = threadIdx.x >> 4, on = threadIdx.x & 15;
+  float cin[2] = {0.f, 0.f};
+  if (EPI == FVQA_EPI_SKINNY_ACC) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (om < M && n0 + 16 * s + on < N) cin[s] = to_f32<TO>(C[(size_t)om * ldc + n0 + 16 * s + on]);
+  }
+  const int lr = lane >> 3, lc = (lane & 7) ^ lr;            // DMA lane: row within an 8-row piece, SOURCE chunk of its slot
+  // source of block b (0, 1: the two weight strips; 2: the activation rows), range e, half h (rows 8h .. 8h + 7), stage 0
+  const bf16_t* src[3][2][2];
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        int bn = n0 + 16 * s + 8 * h + lr; bn = bn < N ? bn : N - 1;
+        src[s][e][h] = B + (size_t)bn * ldb + (size_t)(w + 4 * e) * kw + 8 * lc;
+      }
+      int am = 8 * h + lr; am = am < M ? am : M - 1;
+      src[2][e][h] = A + (size_t)am * lda + (size_t)(w + 4 * e) * kw + 8 * lc;
+    }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) acc[s][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  char* const myring = ring + w * (S * FVQA_SKINNY_DMA_WSTAGE);
+  // fragment read offset inside a (block, range) pair of 1-KiB pieces: row li -> piece li >> 3, row-in-piece li & 7
+  const int r8 = li & 7;
+  const int rd0 = (li >> 3) * 1024 + r8 * 128 + (((0 + g) ^ r8) << 4);      // k-step 0: chunk g
+  const int rd1 = (li >> 3) * 1024 + r8 * 128 + (((4 + g) ^ r8) << 4);      // k-step 1: chunk 4 + g
+  auto issue = [&](int t) {                                  // one group: GROUP LDS-DMA pieces into slot t % S
+    char* dst = myring + (t % S) * FVQA_SKINNY_DMA_WSTAGE;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          __builtin_amdgcn_global_load_lds((gptr_t*)(src[b][e][h] + (size_t)t * 64), (lptr_t*)(dst + ((b * 2 + e) * 2 + h) * 1024), 16, 0,
+                                           FVQA_SKINNY_DMA_AUX);
+  };
+  // wait until the group of stage t has landed: `later` groups were issued after it (GROUP operations each, retired in order)
+  auto landed = [&](int later) {
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_assert(GROUP == 12 && S == 3, "the counted waits above are written for two groups of 12 in flight");
+  auto compute = [&](int t) {
+    const char* slot = myring + (t % S) * FVQA_SKINNY_DMA_WSTAGE;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const char* ablk = slot + (2 * 2 + e) * 2048;
+      const uint4 x0 = *reinterpret_cast<const uint4*>(ablk + rd0), x1 = *reinterpret_cast<const uint4*>(ablk + rd1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const char* blk = slot + (s * 2 + e) * 2048;
+        const uint4 f0 = *reinterpret_cast<const uint4*>(blk + rd0), f1 = *reinterpret_cast<const uint4*>(blk + rd1);
+        acc[s][e] = FVQA_MFMA_H16_16x16x32(__builtin_bit_cast(h16x8_t, f0), __builtin_bit_cast(h16x8_t, x0), acc[s][e], 0, 0, 0);
+        acc[s][e] = FVQA_MFMA_H16_16x16x32(__builtin_bit_cast(h16x8_t, f1), __builtin_bit_cast(h16x8_t, x1), acc[s][e], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot's reads have returned before a later group refills it
+  };
+  // (everything the wave has in flight — the tile's stores, the rows above — leaves the count before the first group enters it)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (0 < nst) issue(0);
+  if (1 < nst) issue(1);
+  for (int t = 0; t < nst; ++t) {
+    if (t + 2 < nst) issue(t + 2);                           // into the slot stage t - 1 has just left
+    const int later = nst - 1 - t;
+    landed(later < 2 ? later : 2);
+    compute(t);
+  }
+  __syncthreads();                                           // every wave is done with its ring: `part` may take its place
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[s][w + 4 * e][li][4 * g + r] = acc[s][e][r];      // [strip][K range][m][n]
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int n = n0 + 16 * s + on;
+    if (om < M && n < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) v += part[s][ww][om][on];
+      if (EPI == FVQA_EPI_SKINNY_ACC) v += cin[s];
+      C[(size_t)om * ldc + n] = from_f32<TO>(v);
+    }
+  }
+}

@@ -90,10 +90,16 @@ class Case:
         if self.kind == "rope":
             ops.gemm_nt_rope(self.a, self.b, self.out, self.rope, self.S, self.Dh, self.H)
         elif self.kind == "swf":
-            ops.gemm_nt_swiglu_fwd(self.a, self.b, self.out, self.z, st=True, rider_a=self.ra, rider_b=self.rb, rider_out=self.ro)
+            if os.environ.get("GW_NO_RIDER") == "1":
+                ops.gemm_nt_swiglu_fwd(self.a, self.b, self.out, self.z, st=True)
+            else:
+                ops.gemm_nt_swiglu_fwd(self.a, self.b, self.out, self.z, st=True, rider_a=self.ra, rider_b=self.rb, rider_out=self.ro)
         elif self.kind == "swb":
-            ops.gemm_nt_rider(self.a, self.b, self.out, rider_a=self.ra, rider_b=self.rb, rider_out=self.ro, accumulate=True,
-                              swiglu_ab=self.st, swiglu_st=True)
+            if os.environ.get("GW_NO_RIDER") == "1":        # what the launch costs without its side job (what a faster rider could win)
+                ops.gemm_nt_swiglu_bwd(self.a, self.b, self.st, self.out, st=True)
+            else:
+                ops.gemm_nt_rider(self.a, self.b, self.out, rider_a=self.ra, rider_b=self.rb, rider_out=self.ro, accumulate=True,
+                                  swiglu_ab=self.st, swiglu_st=True)
         else:
             ops.gemm_nt(self.a, self.b, self.out, residual=getattr(self, "res", None))
 

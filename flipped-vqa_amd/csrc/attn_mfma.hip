@@ -41,6 +41,15 @@ constexpr int BQ = 128;                 // queries / keys per workgroup = rows p
 #define FVQA_ATTN_LDR 144
 #endif
 constexpr int LDR = FVQA_ATTN_LDR;      // row-major tile leading dim (bf16 elements)
+// fp32 partial blocks of the adapter keys' dK / dV ([K range or wave][16 rows][DH]): rows DH + 4 floats apart. With DH floats
+// (512 bytes) every row of a 16-row fragment store started on the same bank — 16-way conflicts on the f32x4 stores, which were the
+// whole 0.28 LDS conflict fraction of the fused backward in rounds 3-4 (r04_pmc_mfma_lds.json) — with 528 bytes the 16 rows of a
+// store spread over all 64 banks.
+#ifdef FVQA_ATTN_ADP_PITCH_OLD            // (A/B builds only: the rounds 1-4 pitch)
+constexpr int ADP_PITCH = DH;
+#else
+constexpr int ADP_PITCH = DH + 4;
+#endif
 constexpr int HP = DH / 2;              // rotation pairs per head
 constexpr float NEG_BIG = -1e30f;
 
@@ -758,14 +767,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
   // adapter block: sum the four working waves' partial blocks through LDS ([4][16][128] fp32 x 2 = 64 KiB, the
   // Q/dO staging area is free now), then one fp32 partial per sequence for the batch reduction
   __syncthreads();
-  float* rK = reinterpret_cast<float*>(smem_raw);
-  float* rV = rK + 4 * 16 * DH;
+  float* rK = reinterpret_cast<float*>(smem_raw);          // [4][16][ADP_PITCH] fp32
+  float* rV = rK + 4 * 16 * ADP_PITCH;
   if (w < 4) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      *reinterpret_cast<f32x4*>(rK + (w * 16 + li) * DH + 16 * d + 4 * g) =
+      *reinterpret_cast<f32x4*>(rK + (w * 16 + li) * ADP_PITCH + 16 * d + 4 * g) =
           f32x4{dk[d][0] * sc, dk[d][1] * sc, dk[d][2] * sc, dk[d][3] * sc};
-      *reinterpret_cast<f32x4*>(rV + (w * 16 + li) * DH + 16 * d + 4 * g) = dv[d];
+      *reinterpret_cast<f32x4*>(rV + (w * 16 + li) * ADP_PITCH + 16 * d + 4 * g) = dv[d];
     }
   }
   __syncthreads();
@@ -774,8 +783,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_mfma_k(
     float sk = 0.f, sv = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) {
-      sk += rK[(ww * 16 + aa) * DH + d];
-      sv += rV[(ww * 16 + aa) * DH + d];
+      sk += rK[(ww * 16 + aa) * ADP_PITCH + d];
+      sv += rV[(ww * 16 + aa) * ADP_PITCH + d];
     }
     const size_t oidx = ((size_t)n * A + aa) * D + h * DH + d;
     dka_part[oidx] = sk;
@@ -829,6 +838,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
   const int gmax = min(4, (S + 31) >> 5);                 // 32-row groups holding real rows
 
   // ---- pass 0: every global load in flight, then rotate + stage
+  uint4 off[4];
   {
     TileRegs<BQ> rQ, rK, rV, rdO;
     TileRegs<16> rKa, rVa;
@@ -844,6 +854,10 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
       lt_in = lse_t[sbase + ii];
       la_in = lse_a[sbase + ii];
     }
+    // (the forward's output rows for the row deltas: requested with everything else, so that their latency runs under the
+    // commits instead of in front of pass A)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) off[ks] = frag_g(o + (size_t)n * S * D + h * DH, (size_t)D, r16c, 32 * ks, lane);
     tile_commit<RIN, BQ>(rQ, sQ, 0, S, cs, sn);
     tile_commit<RIN, BQ>(rK, sK, 0, S, cs, sn);
     tile_commit<false, BQ>(rV, sV, 0, S, nullptr, nullptr);
@@ -855,9 +869,6 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
       sLa[threadIdx.x] = la_in;
     }
   }
-  uint4 off[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) off[ks] = frag_g(o + (size_t)n * S * D + h * DH, (size_t)D, r16c, 32 * ks, lane);
   const float g1 = tanhf(gate1[h]);
   const float g2 = gate2[h];
   const int vs = vstart[n];
@@ -1088,14 +1099,14 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
   }
   __syncthreads();                                        // pass B is done with sK / sV: reuse them
   AT_STAMP(4);
-  float* rK = reinterpret_cast<float*>(sK);               // [4][16][DH] fp32 (32 KiB <= one tile)
+  float* rK = reinterpret_cast<float*>(sK);               // [4][16][ADP_PITCH] fp32 (33 KiB <= one tile)
   float* rV = reinterpret_cast<float*>(sV);
   if (w >= 4) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      *reinterpret_cast<f32x4*>(rK + ((w - 4) * 16 + li) * DH + 16 * d + 4 * g) =
+      *reinterpret_cast<f32x4*>(rK + ((w - 4) * 16 + li) * ADP_PITCH + 16 * d + 4 * g) =
           f32x4{dk[d][0] * sc, dk[d][1] * sc, dk[d][2] * sc, dk[d][3] * sc};
-      *reinterpret_cast<f32x4*>(rV + ((w - 4) * 16 + li) * DH + 16 * d + 4 * g) = dv[d];
+      *reinterpret_cast<f32x4*>(rV + ((w - 4) * 16 + li) * ADP_PITCH + 16 * d + 4 * g) = dv[d];
     }
   }
   __syncthreads();
@@ -1114,8 +1125,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
     float sk = 0.f, sv = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) {
-      sk += rK[(ww * 16 + aa) * DH + d];
-      sv += rV[(ww * 16 + aa) * DH + d];
+      sk += rK[(ww * 16 + aa) * ADP_PITCH + d];
+      sv += rV[(ww * 16 + aa) * ADP_PITCH + d];
     }
     const size_t oidx = ((size_t)n * A + aa) * D + h * DH + d;
     __hip_atomic_store(dka_part + oidx, sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1186,7 +1197,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(
 constexpr size_t FWD_LDS = (size_t)(2 * BQ + 32) * LDR * 2;
 constexpr size_t FUSED_LDS = (size_t)(4 * BQ + 32) * LDR * 2 + 4 * BQ * 4;
 constexpr size_t DKV_LDS = (size_t)2 * BQ * LDR * 2 + 2 * BQ * 4;
-static_assert(DKV_LDS >= (size_t)2 * 4 * 16 * DH * 4, "adapter reduction reuses the staging area");
+static_assert(DKV_LDS >= (size_t)2 * 4 * 16 * ADP_PITCH * 4, "adapter reduction reuses the staging area");
+static_assert((size_t)BQ * LDR * 2 >= (size_t)4 * 16 * ADP_PITCH * 4, "a partial block fits the tile it reuses (fused backward)");
 
 template <typename K>
 void allow_lds(K kernel, size_t bytes) {

@@ -65,6 +65,29 @@ def step_flops(D, H, L, Hf, V, N, S, A, F, tasks):
     return tot
 
 
+def step_roofline_of(fl, ms, peak, model, batches, B, S, tasks):
+    """The whole step against the dense MFMA peak. `frac` prices the step at the ALGORITHMIC FLOPs of SURVEY 8d — the reference's
+    step, LM head at every position (llama/model.py:348-350) — as the contract defines "MFMA % of peak" (its 40 % == 292 samples/s
+    at C2). Since round 5 the step runs the head, the cross-entropy and the head's dX on the rows the cross-entropy scores only
+    (identical losses and gradients; FVQA_LM_HEAD=all restores the dense head): `executed_flops_per_step` / `frac_executed`
+    count what the kernels actually multiplied, so that the skipped rows are not read as matrix-core work."""
+    from fvqa import scored
+    out = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+           "frac": fl / (ms * 1e-3) / peak, "flops_per_step": fl, "lm_head_rows": "all"}
+    lm = [t for t in tasks if t in scored.LM_TASKS]
+    rows = [sum(scored.rows_of(int(b[scored.COUNT][t])) for t in lm) for b in batches if all(t in b.get(scored.COUNT, {}) for t in lm)]
+    if model.ensure_engine().lm_head_rows == "scored" and len(rows) == len(batches):
+        D, V = model.params.dim, model.vocab_size
+        dense = sum(1 for t in tasks if t != "qav") * B * S
+        m = sum(rows) / len(rows)
+        ex = fl - (dense - m) * 2.0 * D * V * 2            # head forward + head dX, per skipped row
+        out.update({"lm_head_rows": "scored", "lm_head_rows_per_step": m, "lm_head_rows_dense": dense,
+                    "executed_flops_per_step": ex, "frac_executed": ex / (ms * 1e-3) / peak,
+                    "note": "frac = SURVEY 8d algorithmic FLOPs (the reference's dense LM head) / time / peak; frac_executed = the "
+                            "FLOPs the kernels ran (head on the scored rows only) / time / peak"})
+    return out
+
+
 def launch_alg_bytes(kind, flops, R, D, Hf, V):
     """Algorithmic bytes of one projection launch of the step, identified by its epilogue kind and FLOP count: operands
     read once + outputs written once (bf16; fp32 logits), epilogue operands included (residual rows; the saved SwiGLU
@@ -74,7 +97,15 @@ def launch_alg_bytes(kind, flops, R, D, Hf, V):
         (5, False): [(2 * Hf, D)], (4, False): [(2 * Hf, D)], (6, False): [(Hf, D)], (3, False): [(Hf, D)],
         (0, True): [(V, D)]}
     epi, f32 = kind & 15, bool(kind & 32)
+    R_all = R
     for (N, K) in shapes.get((epi, f32), []):
+        # the LM head and its dX run on the scored rows only (fvqa/step.py ScoredRows): their row count is the launch's own
+        if epi == 0 and V in (N, K):
+            r = flops / (2.0 * N * K)
+            if abs(r - round(r)) < 1e-6 * max(r, 1.0) and 0 < round(r) <= R_all:
+                R = int(round(r))
+        else:
+            R = R_all
         if abs(2.0 * R * N * K - flops) < 1e-6 * flops:
             b = 2.0 * R * K + 2.0 * N * K + (4.0 if f32 else 2.0) * R * N
             if epi == 1:
@@ -252,6 +283,7 @@ def short_leg(dev, model_name, batch_size, seq_len, vaq, qav, dtype="bf16", step
     import gc
     import util.misc as misc
     from fvqa import synth
+    from fvqa.step import stage_batch
     from fvqa.optim import FusedAdamW, param_groups_weight_decay
     from llama_vqa import LLaMA_VQA
     args = types.SimpleNamespace(
@@ -270,11 +302,8 @@ def short_leg(dev, model_name, batch_size, seq_len, vaq, qav, dtype="bf16", step
                             max_seq_len=seq_len, batch_size=batch_size, vaq=vaq, qav=qav)
     batches = []
     for i in range(4):
-        b = synth.make_batch(cfg, seed=1234 + i)
-        b["video"] = b["video"].to(dev)
-        for k in ("text_id", "label", "video_index"):
-            b[k] = {t: v.to(dev) for t, v in b[k].items()}
-        batches.append(b)
+        # resident batch; the scored-row lists of the LM head are taken while the labels are on the host (fvqa/step.py)
+        batches.append(stage_batch(synth.make_batch(cfg, seed=1234 + i), dev))
 
     def one_step(i):
         opt.zero_grad()
@@ -305,8 +334,7 @@ def short_leg(dev, model_name, batch_size, seq_len, vaq, qav, dtype="bf16", step
                        f"losses={'+'.join(tasks)} fwd+bwd+AdamW, {L} layers",
            "steps": steps, "warmup": warmup, "ms_per_step": ms, "samples_per_s": batch_size * steps / dt,
            "loss": float(loss.detach().sum()),
-           "step_roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
-                             "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / MFMA_BF16_PEAK, "flops_per_step": fl}}
+           "step_roofline": step_roofline_of(fl, ms, MFMA_BF16_PEAK, model, batches, batch_size, seq_len, tasks)}
     if err is not None:
         out["invalid"] = err
     del model, opt, scaler, batches
@@ -361,6 +389,7 @@ def main():
 
     import util.misc as misc
     from fvqa import ops, synth
+    from fvqa.step import stage_batch
     from fvqa.optim import FusedAdamW, param_groups_weight_decay
     from fvqa.parallel import DataParallel
     from llama_vqa import LLaMA_VQA
@@ -395,11 +424,8 @@ def main():
     n_batches = 4
     batches = []
     for i in range(n_batches):
-        b = synth.make_batch(cfg, seed=1234 + rank + world * i)
-        b["video"] = b["video"].to(dev)
-        for k in ("text_id", "label", "video_index"):
-            b[k] = {t: v.to(dev) for t, v in b[k].items()}
-        batches.append(b)
+        # resident batch; the scored-row lists of the LM head are taken while the labels are on the host (fvqa/step.py)
+        batches.append(stage_batch(synth.make_batch(cfg, seed=1234 + rank + world * i), dev))
     torch.cuda.synchronize()
     if rank == 0:
         print(f"[bench] model built in {time.time() - t_build:.1f}s; "
@@ -643,8 +669,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "loss": loss_val,
             "roofline": roof,
-            "step_roofline": {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12,
-                              "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / peak, "flops_per_step": fl},
+            "step_roofline": step_roofline_of(fl, ms, peak, model, batches, a.batch_size, a.seq_len, tasks),
         }
         if comm is not None:
             out["comm"] = comm

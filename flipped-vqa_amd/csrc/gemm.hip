@@ -235,9 +235,16 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
                       const fvqa_sk_rider* rider, int* rode, void* C2 = nullptr, const fvqa_sk_rope* rope = nullptr);
 
+// Problems the persistent family (gemm_sk.hip / gemm4w.hip) takes under variant 0: whole 256-row tiles — or ONE ragged row tile over a
+// large weight matrix (round 5: the LM head and its dX on the scored rows only, M a few dozen to a few hundred, N·K = 131 M: the
+// launch streams the weights once, 70-100 us, where the 128x128 kernel below needs 85 / 590)
+static inline bool persistent_shape(int M, int N, int K) {
+  return N >= 256 && (M >= 192 || (M > 16 && (size_t)N * (size_t)K >= (size_t)100000000));
+}
+
 extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {
-  (void)K; (void)dtype;
-  return (M >= 192 && N >= 256) ? fvqa_gemm_sk_workspace() : 0;
+  (void)dtype;
+  return persistent_shape(M, N, K) ? fvqa_gemm_sk_workspace() : 0;
 }
 
 // variant: 0 = auto — the persistent 256-row kernel (gemm_sk.hip) for large problems it can store in whole 16-byte
@@ -266,7 +273,7 @@ extern "C" int fvqa_gemm_nt(const void* A, const void* B, void* C, const void* R
                      (((uintptr_t)C | (uintptr_t)R) & 15) == 0 && workspace != nullptr &&
                      ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= fvqa_gemm_sk_workspace();
   if (variant == 13 && !sk_ok) return FVQA_EALIGN;
-  if (variant == 13 || (variant == 0 && sk_ok && ((M >= 192 && N >= 256) || swb)))
+  if (variant == 13 || (variant == 0 && sk_ok && (persistent_shape(M, N, K) || swb)))
     return fvqa_gemm_sk_impl(A, B, C, R, workspace, workspace_bytes, M, N, K, lda, ldb, ldc, dtype, out_dtype, epilogue, st,
                              nullptr, nullptr);
   if (swb) return FVQA_EALIGN;                                // that epilogue lives in the persistent kernel only

@@ -135,7 +135,9 @@ extern "C" int fvqa_gemm4w_choose(int M, int N, int K, int dtype, int out_dtype,
   if (epilogue != FVQA_EPI_NONE && epilogue != FVQA_EPI_RESIDUAL && epilogue != FVQA_EPI_ROPE &&
       epilogue != FVQA_EPI_SWIGLU_FWD_ST && epilogue != FVQA_EPI_SWIGLU_BWD_ST)
     return 0;
-  if (M < 192 || N < 256 || (K % 64) || (N & 7) || n_cu < 8 || n_cu > 256) return 0;
+  // (a single ragged row tile over a large weight matrix — the LM head on the scored rows — is a weight stream: its too)
+  const bool stream1 = M > 16 && M < 192 && (size_t)N * (size_t)K >= (size_t)100000000 && epilogue == FVQA_EPI_NONE;
+  if ((M < 192 && !stream1) || N < 256 || (K % 64) || (N & 7) || n_cu < 8 || n_cu > 256) return 0;
   static const char* force = getenv("FVQA_GEMM4W_NBT");
   const int forced = g_force_nbt ? g_force_nbt : (force && force[0] ? atoi(force) : 0);
   int best = 0;

@@ -256,6 +256,32 @@ __global__ __launch_bounds__(256) void cast_rows_k(const float* __restrict__ src
   }
 }
 
+// Row gather / scatter for the LM head on the scored rows only (a row of the batch is scored when the label that follows it is
+// not the ignore index: reference llama/model.py:348-350 evaluates the head at every position and lets the CE ignore the rest).
+// 16-byte accesses; one workgroup per destination row.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_k(const T* __restrict__ src, const int32_t* __restrict__ idx,
+                                                     T* __restrict__ dst, int src_rows, int dim) {
+  constexpr int E = 16 / sizeof(T);
+  const int r = idx[blockIdx.x];
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)r * dim);
+  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.x * dim);
+  const bool ok = r >= 0 && r < src_rows;                 // (block-uniform) an index outside the source reads as a zero row
+  for (int c = threadIdx.x; c < dim / E; c += 256) d[c] = ok ? s[c] : uint4{0u, 0u, 0u, 0u};
+}
+
+// dst row r <- src row inv[r], or zeros where inv[r] < 0 (every destination row is written exactly once: no atomics, no pre-clear)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_k(const T* __restrict__ src, const int32_t* __restrict__ inv,
+                                                      T* __restrict__ dst, int src_rows, int dim) {
+  constexpr int E = 16 / sizeof(T);
+  const int j = inv[blockIdx.x];
+  const bool ok = j >= 0 && j < src_rows;
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)(ok ? j : 0) * dim);
+  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.x * dim);
+  for (int c = threadIdx.x; c < dim / E; c += 256) d[c] = ok ? s[c] : uint4{0u, 0u, 0u, 0u};
+}
+
 inline int grid_for(size_t n_items) {
   size_t g = (n_items + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -356,6 +382,32 @@ extern "C" int fvqa_splice_bwd(const void* dh, const int64_t* index, float* d_to
   if (mode == 0 && (vstart < 0 || vstart + max_feats > seq_len)) return FVQA_ESHAPE;
   DISPATCH_T(dtype, hipLaunchKernelGGL(splice_bwd_k<T>, dim3(n_seq * max_feats), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dh, index, d_tok, n_seq, seq_len, dim, max_feats, vstart, mode));
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_gather_rows(const void* src, const int32_t* idx, void* dst, int src_rows, int n_idx, int dim, int dtype,
+                                void* stream) {
+  if (!src || !idx || !dst) return FVQA_EINVAL;
+  if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
+  const int e = 16 / (int)fvqa_dtype_size(dtype);
+  if (src_rows <= 0 || n_idx <= 0 || dim <= 0 || dim % e) return FVQA_ESHAPE;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0) return FVQA_EALIGN;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gather_rows_k<T>, dim3(n_idx), dim3(256), 0, (hipStream_t)stream, (const T*)src, idx,
+                                       (T*)dst, src_rows, dim));
+  FVQA_CHECK_LAUNCH();
+  return FVQA_OK;
+}
+
+extern "C" int fvqa_scatter_rows(const void* src, const int32_t* inv, void* dst, int src_rows, int dst_rows, int dim, int dtype,
+                                 void* stream) {
+  if (!src || !inv || !dst) return FVQA_EINVAL;
+  if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
+  const int e = 16 / (int)fvqa_dtype_size(dtype);
+  if (src_rows <= 0 || dst_rows <= 0 || dim <= 0 || dim % e) return FVQA_ESHAPE;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0) return FVQA_EALIGN;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(scatter_rows_k<T>, dim3(dst_rows), dim3(256), 0, (hipStream_t)stream, (const T*)src, inv,
+                                       (T*)dst, src_rows, dim));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST = 0, 1, 3, 6
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -61,6 +61,8 @@ SIGNATURES = {
     "fvqa_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p]),
     "fvqa_scaler_update": (_i, [_p, _p, _p, _p, _f, _f, _i, _p]),
     "fvqa_cast_rows": (_i, [_p, _p, _i, _i, _i, _p]),
+    "fvqa_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fvqa_scatter_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "fvqa_layers_gemm_workspace": (_sz, [_p]),
     "fvqa_layers_fwd": (_i, [_p, _p]),
     "fvqa_layers_bwd": (_i, [_p, _p, _p, _p]),

@@ -19,9 +19,13 @@ import numpy as np
 import torch
 
 _ALIGN = 256
-TENSOR_FIELDS = ("text_id", "label", "video_index", "label_mask")     # dicts over tasks
+from . import scored
+
+# dicts over tasks (scored_*: the scored-row lists of the LM streams, fvqa/scored.py — made here, where the labels are on the host,
+# so that the step's LM head can run on the scored rows without another copy or a read-back)
+TENSOR_FIELDS = ("text_id", "label", "video_index", "label_mask") + scored.FIELDS
 PLAIN_FIELDS = ("video", "video_len", "answer", "qtype")              # plain tensors
-HOST_FIELDS = ("video_start", "prefix_index", "vid", "text", "qid")   # stay on the host
+HOST_FIELDS = ("video_start", "prefix_index", "vid", "text", "qid", scored.COUNT)   # stay on the host
 
 
 def _tensor_items(batch: dict) -> List[Tuple[Tuple[str, Optional[str]], torch.Tensor]]:
@@ -54,7 +58,7 @@ class _PackingCollate:
         self.collate_fn = collate_fn
 
     def __call__(self, samples):
-        batch = self.collate_fn(samples)
+        batch = scored.annotate(self.collate_fn(samples))
         items = _tensor_items(batch)
         meta, off = {}, 0
         for key, v in items:
@@ -156,6 +160,8 @@ class DeviceBatchProducer:
                     if stop.is_set():
                         return
                     packed = isinstance(batch, PackedBatch)
+                    if not packed:
+                        batch = scored.annotate({k: (dict(v) if isinstance(v, dict) else v) for k, v in batch.items()})
                     if self._layout is None:
                         if packed:
                             self._layout = ([], int(batch.blob.numel()))

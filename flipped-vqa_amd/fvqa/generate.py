@@ -33,8 +33,9 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
     sub = {"video": data["video"],
            "text_id": {"vqa": ids_all[:, 0:1]}, "label": {"vqa": data["label"]["vqa"][:, 0:1]},
            "video_start": {"vqa": data["video_start"]["vqa"], "vaq": data["video_start"]["vqa"]}}
-    saved = (eng.tasks, eng.n_streams, eng._arena, eng._vstart)
+    saved = (eng.tasks, eng.n_streams, eng._arena, eng._vstart, eng.lm_head_rows)
     eng.tasks, eng.n_streams, eng._arena, eng._vstart = ["vqa"], 1, eng._gen_arena, {}
+    eng.lm_head_rows = "all"                                # the prefill's logits are read at the prefix positions: every row
     try:
         eng.forward(sub)                                    # prefill: logits of every position + KV of every layer
         ar = eng.arena(B, S)
@@ -77,7 +78,7 @@ def greedy_decode(eng, data: dict, n_new: int = N_NEW) -> torch.Tensor:
         return ids
     finally:
         eng._gen_arena = eng._arena
-        eng.tasks, eng.n_streams, eng._arena, eng._vstart = saved
+        eng.tasks, eng.n_streams, eng._arena, eng._vstart, eng.lm_head_rows = saved
 
 
 @torch.no_grad()

@@ -390,6 +390,28 @@ def swiglu_bwd(dz, ab, dab, rows: int, hidden: int):
     return dab
 
 
+def gather_rows(src, idx, dst):
+    """dst (n, dim) row j <- src row idx[j] (int32 device indices; an index outside src gives a zero row)."""
+    _dev(src, idx, dst)
+    _need(src.dim() == 2 and dst.dim() == 2 and src.dtype == dst.dtype and src.shape[1] == dst.shape[1], "gather_rows: shape")
+    _need(idx.dtype == torch.int32 and idx.dim() == 1 and idx.numel() == dst.shape[0], "gather_rows: idx")
+    rc = _lib.load(src.dtype).fvqa_gather_rows(_ptr(src), _ptr(idx), _ptr(dst), src.shape[0], dst.shape[0], src.shape[1],
+                                               dt_code(src.dtype), _stream())
+    _lib.check(rc, "fvqa_gather_rows")
+    return dst
+
+
+def scatter_rows(src, inv, dst):
+    """dst (rows, dim) row r <- src row inv[r], zeros where inv[r] < 0 (int32 device array, one entry per dst row)."""
+    _dev(src, inv, dst)
+    _need(src.dim() == 2 and dst.dim() == 2 and src.dtype == dst.dtype and src.shape[1] == dst.shape[1], "scatter_rows: shape")
+    _need(inv.dtype == torch.int32 and inv.dim() == 1 and inv.numel() == dst.shape[0], "scatter_rows: inv")
+    rc = _lib.load(src.dtype).fvqa_scatter_rows(_ptr(src), _ptr(inv), _ptr(dst), src.shape[0], dst.shape[0], src.shape[1],
+                                                dt_code(src.dtype), _stream())
+    _lib.check(rc, "fvqa_scatter_rows")
+    return dst
+
+
 def cast_rows(src, dst_rows):
     """dst_rows (n, dim) storage dtype <- src (n, dim) fp32."""
     _dev(src, dst_rows)

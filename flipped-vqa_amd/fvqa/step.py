@@ -21,9 +21,38 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import _lib, ops
+from . import _lib, ops, scored
 
 TASKS = ("vqa", "vaq", "qav")
+class ScoredRows:
+    """The scored-row lists (fvqa/scored.py) of the LM streams one engine runs, on its device, with the segments of the compact
+    layout: stream k's rows sit at [offset_k, offset_k + rows_k) of the gathered matrix."""
+
+    def __init__(self, batch: dict, lm_tasks, device):
+        self.idx, self.inv, self.lab, self.segs, self.counts = [], [], [], [], []
+        off = 0
+        for t in lm_tasks:
+            m = int(batch[scored.COUNT][t])
+            rows = scored.rows_of(m)
+            mv = lambda x: x if x.device == device else x.to(device, non_blocking=True)        # noqa: E731
+            self.idx.append(mv(batch["scored_idx"][t]).reshape(-1)[:rows])
+            self.inv.append(mv(batch["scored_inv"][t]).reshape(-1))
+            self.lab.append(mv(batch["scored_lab"][t]).reshape(-1)[:rows])
+            self.segs.append((off, rows))
+            self.counts.append(m)
+            off += rows
+        self.M = off
+
+
+def stage_batch(data: dict, device) -> dict:
+    """A batch dict (dataloader/__init__.py:28-90 schema, host tensors) moved to `device` for a resident-batch loop, the
+    scored-row lists of its LM streams (fvqa/scored.py) taken while the labels are on the host and moved with the rest."""
+    out = scored.annotate({k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items()})
+    out["video"] = out["video"].to(device)
+    for k in ("text_id", "label", "video_index") + scored.FIELDS:
+        if k in out:
+            out[k] = {t: v.to(device) for t, v in out[k].items()}
+    return out
 
 
 class FrozenPack:
@@ -95,13 +124,14 @@ class Arena:
         self.xnf = e(R, D)
         self.rstdN = e(R, dtype=f32)
         self.n_lm = n_lm                        # sequences scored by the LM head (vqa [+ vaq])
-        self.logits = e(n_lm * S, V, dtype=f32)
+        self._e, self._V = e, V
+        self._logits = self._dlogits = None     # dense head (FVQA_LM_HEAD=all, parity of the logits): allocated on first use
+        self._compact_cap = 0                   # scored-rows head: buffers of `cap` compact rows, grown on demand
         self.lse = e(R, dtype=f32)
         self.rowloss = e(R, dtype=f32)
         self.probs = e(R * c.F, dtype=f32)
         self.loss_sum = torch.zeros(3, 2, dtype=f32, device=dev)
         # backward scratch
-        self.dlogits = e(n_lm * S, V)
         self.dxnf = e(R, D)
         self.da = e(R, D)
         self.db = e(R, D)
@@ -117,6 +147,30 @@ class Arena:
         self.gscale = e(3, dtype=f32)
         ws = ops.attn_bwd_workspace(n_seq, S, H, c.Dh, A)
         self.attn_ws = torch.zeros(ws, dtype=torch.uint8, device=dev)   # arrival counters start at zero
+
+
+    @property
+    def logits(self):
+        if self._logits is None:
+            self._logits = self._e(self.n_lm * self.S, self._V, dtype=torch.float32)
+        return self._logits
+
+    @property
+    def dlogits(self):
+        if self._dlogits is None:
+            self._dlogits = self._e(self.n_lm * self.S, self._V)
+        return self._dlogits
+
+    def compact(self, M: int, D: int):
+        """Buffers of the scored-rows head for M compact rows (gathered inputs, logits, their gradients)."""
+        if M > self._compact_cap:
+            cap = (M + 63) // 64 * 64
+            e, V, f32 = self._e, self._V, torch.float32
+            self.xg, self.dxg = e(cap, D), e(cap, D)
+            self.logits_c, self.dlogits_c = e(cap, V, dtype=f32), e(cap, V)
+            self.lse_c, self.rowloss_c = e(cap, dtype=f32), e(cap, dtype=f32)
+            self._compact_cap = cap
+        return self
 
 
 def eng_frames(c, n_seq):
@@ -153,7 +207,10 @@ class StepEngine:
         self._gen_arena: Dict[tuple, Arena] = {}     # arenas of the generation path (VQA stream only)
         self._vstart: Dict[tuple, torch.Tensor] = {}
         self.saved = None
+        self.last_scored = None
         self.keep_logits = False
+        # "scored": head, CE and head dX on the rows the CE scores (ScoredRows); "all": every position, as the reference
+        self.lm_head_rows = "all" if os.environ.get("FVQA_LM_HEAD", "scored") == "all" else "scored"
 
     # ------------------------------------------------------------------ native layer schedule
     def layer_plan(self, ar: "Arena", grads: "FlatParams", vstart: torch.Tensor):
@@ -253,6 +310,9 @@ class StepEngine:
         ids = {t: v.to(dev, non_blocking=True).contiguous() for t, v in ids_h.items()}
         labels = {t: data["label"][t].reshape(B, S).to(dev, non_blocking=True).contiguous() for t in self.tasks}
         video_d = video.to(dev, dtype=torch.float32, non_blocking=True).reshape(B * F, -1).contiguous()
+        # (with the other host-to-device copies of the batch, not behind the layers: a pageable copy holds the host until the
+        # stream reaches it)
+        sc = self._scored(data) if self.lm_head_rows == "scored" else None
         qidx = None
         if "qav" in self.tasks:
             qi = data["video_index"]["qav"]
@@ -285,19 +345,43 @@ class StepEngine:
         else:
             self._layers_fwd_py(ar, vstart, n_seq, S)
         n_lm = ar.n_lm
-        ops.gemm_nt(ar.xnf[: n_lm * S], pk.wout, ar.logits)
         ar.loss_sum.zero_()
+        if sc is not None:
+            # LM head on the scored rows only: gather per stream -> (M, D) x W_out^T -> CE per stream segment (one "sequence" each)
+            ar.compact(sc.M, D)
+            xg, lg = ar.xg[: sc.M], ar.logits_c[: sc.M]
+            for k, (o0, rows_k) in enumerate(sc.segs):
+                ops.gather_rows(ar.xnf[k * B * S:(k + 1) * B * S], sc.idx[k], xg[o0:o0 + rows_k])
+            ops.gemm_nt(xg, pk.wout, lg)
+            for k, (o0, rows_k) in enumerate(sc.segs):
+                seg = slice(o0, o0 + rows_k)
+                ops.ce_fwd(lg[seg], sc.lab[k], ar.lse_c[seg], ar.rowloss_c[seg], ar.loss_sum[k], 1, rows_k, V, 0)
+        else:
+            ops.gemm_nt(ar.xnf[: n_lm * S], pk.wout, ar.logits)
         for k, t in enumerate(self.tasks):
             rows = slice(k * B * S, (k + 1) * B * S)
             if t == "qav":
                 ops.qav_head_fwd(ar.xnf[rows], vf_raw, labels[t], ar.probs[k * B * S * F:], ar.rowloss[rows],
                                  ar.loss_sum[2], B, S, D, F, self.tau)
-            else:
+            elif sc is None:
                 ops.ce_fwd(ar.logits[rows], labels[t], ar.lse[rows], ar.rowloss[rows], ar.loss_sum[k], B, S, V, 0)
         self.saved = dict(ar=ar, B=B, S=S, vs=vs, labels=labels, qidx=qidx, video=video_d, vf_raw=vf_raw,
-                          vstart=vstart)
+                          vstart=vstart, scored=sc)
+        self.last_scored = sc                                   # (tests: which rows the compact logits belong to)
         losses = ar.loss_sum[:, 0] / ar.loss_sum[:, 1]        # mean over scored rows (NaN if none, as torch CE)
         return losses
+
+    def _scored(self, data: dict) -> Optional[ScoredRows]:
+        """The batch's scored-row lists on the device. They come with the batch (the batch producer and stage_batch make them
+        where the labels are on the host) or are made here from host labels; None — the dense head — for device labels without
+        lists: reading them back would stall the step."""
+        lm = tuple(t for t in self.tasks if t in scored.LM_TASKS)
+        have = data.get(scored.COUNT, {})
+        if not all(t in have for t in lm):
+            if any(data["label"][t].is_cuda for t in lm):
+                return None
+            data = scored.annotate({"label": {t: data["label"][t] for t in lm}})
+        return ScoredRows(data, lm, self.device)
 
     def _layers_fwd_py(self, ar, vstart, n_seq, S):
         """The same layer walk as csrc/schedule.hip, one ctypes call per kernel."""
@@ -361,15 +445,26 @@ class StepEngine:
         has_qav = "qav" in self.tasks
         if has_qav:
             ar.d_qav.zero_()
+        sc = sv.get("scored")
         for k, t in enumerate(self.tasks):
             rows = slice(k * B * S, (k + 1) * B * S)
             if t == "qav":
                 ops.qav_head_bwd(ar.xnf[rows], sv["vf_raw"], labels[t], ar.probs[k * B * S * F:], ar.loss_sum[2],
                                  ar.gscale[2:3], ar.dxnf[rows], ar.d_qav, B, S, D, F, self.tau)
-            else:
+            elif sc is None:
                 ops.ce_bwd(ar.logits[rows], labels[t], ar.lse[rows], ar.loss_sum[k], ar.gscale[k:k + 1],
                            ar.dlogits[rows], B, S, V, 0)
-        ops.gemm_nt(ar.dlogits, pk.wout_t, ar.dxnf[: ar.n_lm * S])
+        if sc is not None:
+            # d(logits) of the scored rows -> their dX rows through W_out -> scattered under the zero rows of everything else
+            lg, dlg, dxg = ar.logits_c[: sc.M], ar.dlogits_c[: sc.M], ar.dxg[: sc.M]
+            for k, (o0, rows_k) in enumerate(sc.segs):
+                seg = slice(o0, o0 + rows_k)
+                ops.ce_bwd(lg[seg], sc.lab[k], ar.lse_c[seg], ar.loss_sum[k], ar.gscale[k:k + 1], dlg[seg], 1, rows_k, V, 0)
+            ops.gemm_nt(dlg, pk.wout_t, dxg)
+            for k, (o0, rows_k) in enumerate(sc.segs):
+                ops.scatter_rows(dxg[o0:o0 + rows_k], sc.inv[k], ar.dxnf[k * B * S:(k + 1) * B * S])
+        else:
+            ops.gemm_nt(ar.dlogits, pk.wout_t, ar.dxnf[: ar.n_lm * S])
         if self.use_native_schedule():
             plan = self.layer_plan(ar, grads, sv["vstart"])
             out = C.c_void_p()

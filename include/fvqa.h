@@ -73,7 +73,8 @@ const char* fvqa_arch(void); /* "gfx950"                                     */
  * tail[(m - m_split)*N + n] (ACCUMULATED, +=) instead of C (adapter-query gradient rows).
  * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows.
  * variant 0 picks the kernel: the persistent 256x256-tile LDS-DMA ring kernel (M >= 192, N >= 256, N % 8 == 0, no
- * tail rows, workspace given), the weight-streaming kernel of the generation path for bf16 M <= 16, K % 256 == 0 (one
+ * tail rows, workspace given; also 16 < M < 192 against >= 100 M weights: the LM head and its dX on the scored rows of a
+ * batch, llama/model.py:348-350), the weight-streaming kernel of the generation path for bf16 M <= 16, K % 256 == 0 (one
  * new token per sequence, llama/model.py:439-447 run row-wise; with C == NULL, m_split == 0 it accumulates every row
  * into `tail`: the adapter-query gradient rows), else the 128x128-tile kernel. Other variant codes force a kernel
  * (1 / 2 = 128x128 register- / DMA-staged, 12 = weight-streaming, 13 = persistent; tests, tuning). */
@@ -412,6 +413,18 @@ int fvqa_layers_bwd(const fvqa_layer_plan* plan, const void* dxnf, void** d_x0, 
  * dst rows [row0, row0+n_rows) of a (.., dim) storage-dtype matrix <- fp32 src (n_rows, dim)
  * (adapter_query rows appended under the normed activations, llama/model.py:339) */
 int fvqa_cast_rows(const float* src, void* dst, int n_rows, int dim, int dtype, void* stream);
+
+/* ---- LM head on the scored rows only ---------------------------------------------------------
+ * The reference evaluates `output` at every position and lets the cross-entropy ignore the rows whose next label is 0
+ * (llama/model.py:348-350). A row that is ignored contributes neither to the loss nor to any gradient,
+ * so the step gathers the scored rows of the final-norm output, runs the head and its dX on those (fvqa_gemm_nt), and
+ * scatters the gradient rows back; results are those of the dense form.
+ *   gather : dst (n_idx, dim) row j <- src row idx[j]            (an index outside [0, src_rows) gives a zero row)
+ *   scatter: dst (dst_rows, dim) row r <- src row inv[r], zeros where inv[r] < 0 (every row written once; no pre-clear)
+ * idx / inv: int32 device arrays; rows 16-byte aligned, dim a multiple of 16 bytes. */
+int fvqa_gather_rows(const void* src, const int32_t* idx, void* dst, int src_rows, int n_idx, int dim, int dtype, void* stream);
+int fvqa_scatter_rows(const void* src, const int32_t* inv, void* dst, int src_rows, int dst_rows, int dim, int dtype,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,8 +40,13 @@ def build_model(cfg, dtype=torch.float32, device="cuda"):
     return model, args
 
 
-def run_step(model, batch, loss_weights=(1.0, 1.0, 1.0)):
-    """forward + backward of w·losses; returns losses dict, grads dict (CPU fp32), logits dict, layer outs."""
+def run_step(model, batch, loss_weights=(1.0, 1.0, 1.0), lm_head="all"):
+    """forward + backward of w·losses; returns losses dict, grads dict (CPU fp32), logits dict, layer outs.
+
+    lm_head: "all" = the LM head at every position, as the reference evaluates it (the parity tests compare the logits of every
+    row); "scored" = the product default, head + CE + head dX on the scored rows only (fvqa/step.py ScoredRows) — the logits
+    dict then holds NaN rows wherever the cross-entropy ignores the row."""
+    model.ensure_engine().lm_head_rows = lm_head
     flat = model.flat_params()
     flat.zero_grad()
     vqa, vaq, qav = model(batch)
@@ -60,9 +65,17 @@ def run_step(model, batch, loss_weights=(1.0, 1.0, 1.0)):
               "qav": float(qav.detach()) if model.args.qav else 0.0}
     grads = {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
     logits = {}
+    sc = eng.last_scored
     for k, t in enumerate(eng.tasks):
-        if t != "qav":
+        if t == "qav":
+            continue
+        if sc is None:
             logits[t] = ar.logits[k * B * S:(k + 1) * B * S].view(B, S, -1).float().cpu()
+        else:
+            o0, m = sc.segs[k][0], sc.counts[k]
+            full = torch.full((B * S, eng.V), float("nan"))
+            full[sc.idx[k][:m].long().cpu()] = ar.logits_c[o0:o0 + m].float().cpu()
+            logits[t] = full.view(B, S, -1)
     layer_out = []
     for i in range(eng.L):
         for k, t in enumerate(eng.tasks):

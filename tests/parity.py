@@ -57,13 +57,15 @@ def rel_err(a, b):
 
 
 def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, tol=None, check_argmax=True,
-                        min_decided=0.0):
+                        min_decided=0.0, scored_rows_only=False):
     """losses: dict task->float; grads: dict name->tensor (CPU); logits: dict task->(N,S,V) tensor;
     layer_out: list in the reference's hook order (layer-major, stream-minor) of (N,S,D) tensors.
     rtol bounds every quantity unless `tol` gives its own bound for "loss" / "logits" / "layer" / "grad".
     Token argmax must equal the reference's on every DECIDED row: a row whose reference top-2 margin exceeds the band
     the MEASURED logit error allows (8 x the largest sampled error, at least 2e-5 of the logit range) — rows inside
     that band are ties, not mismatches; min_decided is the least fraction of rows that must be decided.
+    scored_rows_only: the logits come from the scored-rows LM head (NaN rows wherever the cross-entropy ignores the row): sampled
+    logits and argmax are compared on the rows that exist — at least one sampled logit and one row must.
     Returns a dict of measured errors; raises AssertionError on the first violation."""
     tol = dict(tol or {})
     t_loss, t_logit = tol.get("loss", rtol), tol.get("logits", rtol)
@@ -85,16 +87,30 @@ def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, 
             rows, cols = g[f"sample_rows_{t}"].astype(np.int64), g[f"sample_cols_{t}"].astype(np.int64)
             got = flat[torch.from_numpy(rows), torch.from_numpy(cols)].numpy()
             amax = float(g[f"logits_absmax_{t}"])
-            err = float(np.abs(got - g[f"sample_logits_{t}"]).max() / amax)
+            want = g[f"sample_logits_{t}"]
+            have_row = np.ones(flat.shape[0], dtype=bool)
+            if scored_rows_only:
+                have_row = ~torch.isnan(flat[:, 0]).numpy()
+                assert have_row.any(), f"logits_{t}: no scored row"
+                keep = have_row[rows]
+                if not keep.any():                     # none of the golden's sampled positions is a scored row: compare the
+                    rep[f"logits_{t}"] = float("nan")  # rows through the argmax only (every scored row is checked there)
+                    got, want = got[:0], want[:0]
+                else:
+                    got, want = got[keep], want[keep]
+                assert not np.isnan(flat[torch.from_numpy(np.nonzero(have_row)[0])].numpy()).any(), f"logits_{t}: NaN in a scored row"
+            else:
+                assert not torch.isnan(flat).any(), f"logits_{t}: NaN"
+            err = float(np.abs(got - want).max() / amax) if got.size else 0.0
             rep[f"logits_{t}"] = err
             assert err <= t_logit, f"logits_{t}: max abs err / absmax = {err:.3e} > {t_logit}"
             if check_argmax:
-                am = flat.argmax(-1).numpy()
+                am = torch.nan_to_num(flat, nan=0.0).argmax(-1).numpy()
                 band = max(8.0 * err, 2e-5) * amax
-                decided = g[f"margin_{t}"] > band
+                decided = (g[f"margin_{t}"] > band) & have_row
                 bad = (am != g[f"argmax_{t}"]) & decided
-                frac = float(decided.mean())
-                rep[f"argmax_{t}_decided"] = f"{int(decided.sum())}/{decided.size}"
+                frac = float(decided.sum() / max(1, have_row.sum()))
+                rep[f"argmax_{t}_decided"] = f"{int(decided.sum())}/{int(have_row.sum())}"
                 assert not bad.any(), f"argmax_{t}: {int(bad.sum())} of {int(decided.sum())} decided rows differ"
                 assert frac >= min_decided, f"argmax_{t}: only {frac:.3f} of the rows are decided (band {band:.3e})"
     if layer_out is not None:

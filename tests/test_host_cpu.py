@@ -408,3 +408,43 @@ def test_train_one_epoch_stops_every_rank_on_an_error_lane_set_in_the_last_itera
     assert abs(stats["loss"] - 1.75) < 1e-6
     with pytest.raises(RuntimeError, match="found_inf = 2"):
         engine.train_one_epoch(Model(), [0, 1, 2, 3], opt, 0, Scaler(fault_at=4), args=args)
+
+
+def test_scored_rows_lists_match_the_cross_entropy_rule():
+    """fvqa/scored.py against a plain loop over the reference's rule (llama/model.py:348-350: logits[:, :-1] against label[:, 1:],
+    ignore_index 0): which rows, in which order, their shifted labels, pads and the inverse map."""
+    import torch
+    from fvqa import scored, synth
+    cfg = synth.preset("small", vaq=True, qav=True)
+    batch = synth.make_batch(cfg, seed=2)
+    B, S = batch["video"].shape[0], cfg.max_seq_len
+    batch["label"] = {t: v.clone() for t, v in batch["label"].items()}
+    batch["label"]["vqa"][1] = 0                              # a sample with no scored row
+    batch["label"]["vaq"][0, 0, 7] = -3                       # a negative label is not a class id
+    out = scored.annotate(batch)
+    assert out is batch and set(batch[scored.COUNT]) == {"vqa", "vaq"}
+    for t in ("vqa", "vaq"):
+        L = batch["label"][t].reshape(B, S)
+        want_rows, want_lab = [], []
+        for n in range(B):
+            for p in range(S - 1):
+                if int(L[n, p + 1]) > 0:
+                    want_rows.append(n * S + p)
+                    want_lab.append(int(L[n, p + 1]))
+        m = batch[scored.COUNT][t]
+        idx, inv, lab = (batch[f][t] for f in scored.FIELDS)
+        assert m == len(want_rows) and idx.shape == inv.shape == lab.shape == (B, S)
+        assert idx.dtype == inv.dtype == torch.int32 and lab.dtype == torch.int64
+        rows = scored.rows_of(m)
+        assert rows == m + 1
+        assert idx.view(-1)[:m].tolist() == want_rows and int(idx.view(-1)[m]) == 0
+        assert lab.view(-1)[0] == 0 and lab.view(-1)[1:m + 1].tolist() == want_lab and int(lab.view(-1)[m + 1:].abs().sum()) == 0
+        flat = inv.view(-1)
+        assert [int(flat[r]) for r in want_rows] == list(range(m)) and int((flat >= 0).sum()) == m
+    again = {f: {t: v.clone() for t, v in batch[f].items()} for f in scored.FIELDS}
+    scored.annotate(batch)                                     # idempotent
+    assert all(torch.equal(again[f][t], batch[f][t]) for f in scored.FIELDS for t in again[f])
+    # a stream with no scored row at all keeps a two-row segment (the CE kernels need a "sequence" of >= 2 rows; the loss is 0 / 0
+    # = NaN there, as torch's cross_entropy gives and engine.py:33-35 exits on)
+    idx, inv, lab, m = scored.lists_of(torch.zeros(B, 1, S, dtype=torch.int64))
+    assert m == 0 and scored.rows_of(0) == 2 and int(lab.abs().sum()) == 0 and int((inv >= 0).sum()) == 0

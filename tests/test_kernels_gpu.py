@@ -989,3 +989,38 @@ def test_set_error_word_skips_the_optimizer_step_and_raises():
         word.view(torch.int64)[0] = 0
     step()
     assert scaler._found.item() == 0.0 and not torch.equal(flat.flat, p1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gather_and_scatter_rows(dtype):
+    """fvqa_gather_rows / fvqa_scatter_rows (the scored-rows LM head's row movers): exact copies, zero rows where the index says so."""
+    torch.manual_seed(0)
+    R, D = 300, 4096
+    src = torch.randn(R, D, device="cuda").to(dtype)
+    idx = torch.tensor([5, 0, 299, 17, 17, 123, -1, 300], dtype=torch.int32, device="cuda")
+    dst = torch.full((idx.numel(), D), 7.0, device="cuda").to(dtype)
+    ops.gather_rows(src, idx, dst)
+    for j, r in enumerate(idx.tolist()):
+        want = src[r] if 0 <= r < R else torch.zeros(D, device="cuda", dtype=dtype)
+        assert torch.equal(dst[j], want), (j, r)
+    inv = torch.full((R,), -1, dtype=torch.int32, device="cuda")
+    inv[torch.tensor([3, 250, 299], device="cuda")] = torch.tensor([2, 0, 5], dtype=torch.int32, device="cuda")
+    out = torch.full((R, D), 3.0, device="cuda").to(dtype)
+    ops.scatter_rows(dst, inv, out)
+    ref = torch.zeros_like(out)
+    ref[3], ref[250], ref[299] = dst[2], dst[0], dst[5]
+    assert torch.equal(out, ref)
+
+
+def test_lm_head_on_few_rows_whichever_kernel_takes_it():
+    """Dispatch of fvqa_gemm_nt variant 0 for the scored-rows LM head (N x K = 32000 x 4096): the result must not depend on the
+    route, and every row count between the routes' borders must work."""
+    torch.manual_seed(1)
+    V, D = 32000, 4096
+    w = (torch.randn(V, D, device="cuda") * 0.02).bfloat16()
+    for M in (16, 17, 64, 65, 191, 192):
+        x = torch.randn(M, D, device="cuda").bfloat16()
+        out = torch.empty(M, V, device="cuda", dtype=torch.float32)
+        ops.gemm_nt(x, w, out)
+        ref = x.float() @ w.float().t()
+        assert float((out - ref).abs().max() / ref.abs().max()) < 5e-6, M

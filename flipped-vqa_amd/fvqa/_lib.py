@@ -140,6 +140,14 @@ def load(which=None) -> C.CDLL:
         raise FvqaLibraryError(
             f"{path} not found: build it with `python -m fvqa.build` (hipcc --offload-arch=gfx950). "
             "There is no CPU or PyTorch fallback for the Flipped-VQA hot path.")
+    # The library must share ONE HIP runtime with whoever owns the device memory it is handed. Under PyTorch that is the
+    # libamdhip64 bundled in torch/lib: torch goes first — a library loaded before it pulls /opt/rocm's copy in, the process then
+    # holds two runtimes and every kernel launch of this library fails with hipErrorNoDevice (seen: build() then smoke() in one
+    # process). A host without torch (a C caller of include/fvqa.h) links the system runtime and is not affected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(path)
     except OSError as e:

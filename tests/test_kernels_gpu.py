@@ -3,6 +3,7 @@
 max magnitude (GEMM K<=4096: 5e-5); bf16 build: 2e-2 (8-bit mantissa storage); the fp16 build
 (libfvqa_hip_f16.so: 11-bit mantissa) is held to the bf16 bounds. Run with -m gpu."""
 import math
+import os
 
 import pytest
 import torch
@@ -1024,3 +1025,24 @@ def test_lm_head_on_few_rows_whichever_kernel_takes_it():
         ops.gemm_nt(x, w, out)
         ref = x.float() @ w.float().t()
         assert float((out - ref).abs().max() / ref.abs().max()) < 5e-6, M
+
+
+def test_library_bound_before_torch_is_imported_still_launches():
+    """A process that binds libfvqa_hip.so BEFORE importing torch (build() followed by smoke() did) must end up with ONE HIP runtime:
+    the binding imports torch first. Before the fix every launch of such a process failed with hipErrorNoDevice."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from fvqa import _lib\n"
+        "assert 'torch' not in sys.modules\n"
+        "_lib.load(); _lib.load('f16')\n"
+        "import torch\n"
+        "from fvqa import ops\n"
+        "x = torch.randn(4, 256, device='cuda').bfloat16(); w = torch.ones(256, device='cuda').bfloat16(); y = torch.empty_like(x)\n"
+        "ops.rmsnorm_fwd(x, w, y, None, 1e-6, rows=4); torch.cuda.synchronize()\n"
+        "ref = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)\n"
+        "assert float((y.float() - ref).abs().max()) < 5e-2\n"
+        "print('ok')\n") % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flipped-vqa_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -67,24 +67,30 @@ def step_flops(D, H, L, Hf, V, N, S, A, F, tasks):
 
 def step_roofline_of(fl, ms, peak, model, batches, B, S, tasks):
     """The whole step against the dense MFMA peak. `frac` prices the step at the ALGORITHMIC FLOPs of SURVEY 8d — the reference's
-    step, LM head at every position (llama/model.py:348-350) — as the contract defines "MFMA % of peak" (its 40 % == 292 samples/s
-    at C2). Since round 5 the step runs the head, the cross-entropy and the head's dX on the rows the cross-entropy scores only
-    (identical losses and gradients; FVQA_LM_HEAD=all restores the dense head): `executed_flops_per_step` / `frac_executed`
-    count what the kernels actually multiplied, so that the skipped rows are not read as matrix-core work."""
+    step: every projection of every layer and the LM head at every position (llama/model.py:338-350) — as the contract defines
+    "MFMA % of peak" (its 40 % == 292 samples/s at C2). Since round 5 the step runs the last layer's post-attention half (WO, FFN,
+    final norm), the heads and all of their backward on the rows a head reads only (identical losses and gradients;
+    FVQA_LM_HEAD=all restores the dense form): `executed_flops_per_step` / `frac_executed` count what the kernels actually
+    multiplied, so that the skipped rows are not read as matrix-core work."""
     from fvqa import scored
     out = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
            "frac": fl / (ms * 1e-3) / peak, "flops_per_step": fl, "lm_head_rows": "all"}
-    lm = [t for t in tasks if t in scored.LM_TASKS]
-    rows = [sum(scored.rows_of(int(b[scored.COUNT][t])) for t in lm) for b in batches if all(t in b.get(scored.COUNT, {}) for t in lm)]
-    if model.ensure_engine().lm_head_rows == "scored" and len(rows) == len(batches):
+    have = [b for b in batches if all(t in b.get(scored.COUNT, {}) for t in tasks)]
+    if model.ensure_engine().lm_head_rows == "scored" and len(have) == len(batches):
         D, V = model.params.dim, model.vocab_size
-        dense = sum(1 for t in tasks if t != "qav") * B * S
-        m = sum(rows) / len(rows)
-        ex = fl - (dense - m) * 2.0 * D * V * 2            # head forward + head dX, per skipped row
-        out.update({"lm_head_rows": "scored", "lm_head_rows_per_step": m, "lm_head_rows_dense": dense,
+        Hf = model.layers[0].feed_forward.w1.weight.shape[0]
+        lm = [t for t in tasks if t in scored.LM_TASKS]
+        m_lm = sum(sum(scored.rows_of(int(b[scored.COUNT][t])) for t in lm) for b in have) / len(have)
+        m_all = sum(sum(scored.rows_of(int(b[scored.COUNT][t])) for t in tasks) for b in have) / len(have)
+        dense_lm, dense_all = len(lm) * B * S, len(tasks) * B * S
+        per_row_tail = 2.0 * (2.0 * D * D + 6.0 * D * Hf)     # WO + W1|W3 + W2 of one row, forward; the same again for their dX
+        ex = fl - (dense_lm - m_lm) * 2.0 * D * V * 2 - (dense_all - m_all) * per_row_tail * 2
+        out.update({"lm_head_rows": "scored", "lm_head_rows_per_step": m_lm, "lm_head_rows_dense": dense_lm,
+                    "tail_rows_per_step": m_all, "tail_rows_dense": dense_all,
                     "executed_flops_per_step": ex, "frac_executed": ex / (ms * 1e-3) / peak,
-                    "note": "frac = SURVEY 8d algorithmic FLOPs (the reference's dense LM head) / time / peak; frac_executed = the "
-                            "FLOPs the kernels ran (head on the scored rows only) / time / peak"})
+                    "note": "frac = SURVEY 8d algorithmic FLOPs (the reference's dense step) / time / peak; frac_executed = the "
+                            "FLOPs the kernels ran (last layer's post-attention half and the heads on the rows a head reads only) "
+                            "/ time / peak"})
     return out
 
 
@@ -99,13 +105,12 @@ def launch_alg_bytes(kind, flops, R, D, Hf, V):
     epi, f32 = kind & 15, bool(kind & 32)
     R_all = R
     for (N, K) in shapes.get((epi, f32), []):
-        # the LM head and its dX run on the scored rows only (fvqa/step.py ScoredRows): their row count is the launch's own
-        if epi == 0 and V in (N, K):
-            r = flops / (2.0 * N * K)
-            if abs(r - round(r)) < 1e-6 * max(r, 1.0) and 0 < round(r) <= R_all:
-                R = int(round(r))
-        else:
-            R = R_all
+        # launches of the tail rows (the last layer's post-attention half, the LM head, their dX; fvqa/step.py TailRows) carry their
+        # own row count: a launch of this shape whose FLOPs are a whole number of rows <= the dense count
+        R = R_all
+        r = flops / (2.0 * N * K)
+        if abs(r - round(r)) < 1e-6 * max(r, 1.0) and 0 < round(r) < R_all:
+            R = int(round(r))
         if abs(2.0 * R * N * K - flops) < 1e-6 * flops:
             b = 2.0 * R * K + 2.0 * N * K + (4.0 if f32 else 2.0) * R * N
             if epi == 1:

@@ -236,10 +236,11 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
                       const fvqa_sk_rider* rider, int* rode, void* C2 = nullptr, const fvqa_sk_rope* rope = nullptr);
 
 // Problems the persistent family (gemm_sk.hip / gemm4w.hip) takes under variant 0: whole 256-row tiles — or ONE ragged row tile over a
-// large weight matrix (round 5: the LM head and its dX on the scored rows only, M a few dozen to a few hundred, N·K = 131 M: the
-// launch streams the weights once, 70-100 us, where the 128x128 kernel below needs 85 / 590)
+// weight matrix of a 7B-class layer (>= 16 M elements; round 5: the tail rows — the last layer's post-attention projections, the LM
+// head and their dX on the few dozen to few hundred rows a head reads). Such a launch is a weight stream: every tile cut along K so
+// that 128-256 workgroups pull the matrix once (WO 4096 x 4096 at 33 rows: 128 x 128 kernel 67 us on 32 workgroups; LM head dX 590 us)
 static inline bool persistent_shape(int M, int N, int K) {
-  return N >= 256 && (M >= 192 || (M > 16 && (size_t)N * (size_t)K >= (size_t)100000000));
+  return N >= 256 && (M >= 192 || (M > 16 && (size_t)N * (size_t)K >= ((size_t)1 << 24)));
 }
 
 extern "C" size_t fvqa_gemm_workspace(int M, int N, int K, int dtype) {

@@ -256,28 +256,35 @@ __global__ __launch_bounds__(256) void cast_rows_k(const float* __restrict__ src
   }
 }
 
-// Row gather / scatter for the LM head on the scored rows only (a row of the batch is scored when the label that follows it is
-// not the ignore index: reference llama/model.py:348-350 evaluates the head at every position and lets the CE ignore the rest).
-// 16-byte accesses; one workgroup per destination row.
+// Row movers of the tail rows (include/fvqa.h fvqa_row_segs): the rows a head reads, gathered from / scattered to up to three
+// streams of the dense layout. 16-byte accesses; one workgroup per destination row; the segment table travels by value.
+struct RowSegs {
+  int n, stream_rows;
+  int off[4];
+  const int32_t* map[3];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void gather_rows_k(const T* __restrict__ src, const int32_t* __restrict__ idx,
-                                                     T* __restrict__ dst, int src_rows, int dim) {
+__global__ __launch_bounds__(256) void gather_rows_k(const T* __restrict__ src, T* __restrict__ dst, RowSegs sg, int dim) {
   constexpr int E = 16 / sizeof(T);
-  const int r = idx[blockIdx.x];
-  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)r * dim);
-  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.x * dim);
-  const bool ok = r >= 0 && r < src_rows;                 // (block-uniform) an index outside the source reads as a zero row
+  const int j = blockIdx.x;
+  int k = 0;
+  while (k + 1 < sg.n && j >= sg.off[k + 1]) ++k;                         // (block-uniform; n <= 3)
+  const int r = sg.map[k][j - sg.off[k]];
+  const bool ok = r >= 0 && r < sg.stream_rows;                           // an index outside the stream reads as a zero row
+  const uint4* s = reinterpret_cast<const uint4*>(src + ((size_t)k * sg.stream_rows + (ok ? r : 0)) * dim);
+  uint4* d = reinterpret_cast<uint4*>(dst + (size_t)j * dim);
   for (int c = threadIdx.x; c < dim / E; c += 256) d[c] = ok ? s[c] : uint4{0u, 0u, 0u, 0u};
 }
 
-// dst row r <- src row inv[r], or zeros where inv[r] < 0 (every destination row is written exactly once: no atomics, no pre-clear)
+// dense row <- its compact row, or zeros (every dense row of the n streams is written exactly once: no atomics, no pre-clear)
 template <typename T>
-__global__ __launch_bounds__(256) void scatter_rows_k(const T* __restrict__ src, const int32_t* __restrict__ inv,
-                                                      T* __restrict__ dst, int src_rows, int dim) {
+__global__ __launch_bounds__(256) void scatter_rows_k(const T* __restrict__ src, T* __restrict__ dst, RowSegs sg, int dim) {
   constexpr int E = 16 / sizeof(T);
-  const int j = inv[blockIdx.x];
-  const bool ok = j >= 0 && j < src_rows;
-  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)(ok ? j : 0) * dim);
+  const int k = blockIdx.x / sg.stream_rows, r = blockIdx.x - k * sg.stream_rows;
+  const int j = sg.map[k][r];
+  const bool ok = j >= 0 && j < sg.off[k + 1] - sg.off[k];
+  const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)(sg.off[k] + (ok ? j : 0)) * dim);
   uint4* d = reinterpret_cast<uint4*>(dst + (size_t)blockIdx.x * dim);
   for (int c = threadIdx.x; c < dim / E; c += 256) d[c] = ok ? s[c] : uint4{0u, 0u, 0u, 0u};
 }
@@ -386,28 +393,40 @@ extern "C" int fvqa_splice_bwd(const void* dh, const int64_t* index, float* d_to
   return FVQA_OK;
 }
 
-extern "C" int fvqa_gather_rows(const void* src, const int32_t* idx, void* dst, int src_rows, int n_idx, int dim, int dtype,
-                                void* stream) {
-  if (!src || !idx || !dst) return FVQA_EINVAL;
+static inline int segs_ok(const fvqa_row_segs* g, RowSegs* out) {
+  if (!g || g->n < 1 || g->n > 3 || g->stream_rows <= 0 || g->off[0] != 0) return 0;
+  out->n = g->n; out->stream_rows = g->stream_rows;
+  for (int k = 0; k < 4; ++k) out->off[k] = k <= g->n ? g->off[k] : g->off[g->n];
+  for (int k = 0; k < 3; ++k) out->map[k] = k < g->n ? g->map[k] : nullptr;
+  for (int k = 0; k < g->n; ++k)
+    if (!g->map[k] || g->off[k + 1] < g->off[k]) return 0;
+  return g->off[g->n] > 0;
+}
+
+extern "C" int fvqa_gather_rows(const void* src, void* dst, const fvqa_row_segs* segs, int dim, int dtype, void* stream) {
+  if (!src || !dst) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
+  RowSegs sg;
+  if (!segs_ok(segs, &sg)) return FVQA_EINVAL;
   const int e = 16 / (int)fvqa_dtype_size(dtype);
-  if (src_rows <= 0 || n_idx <= 0 || dim <= 0 || dim % e) return FVQA_ESHAPE;
+  if (dim <= 0 || dim % e) return FVQA_ESHAPE;
   if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0) return FVQA_EALIGN;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(gather_rows_k<T>, dim3(n_idx), dim3(256), 0, (hipStream_t)stream, (const T*)src, idx,
-                                       (T*)dst, src_rows, dim));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gather_rows_k<T>, dim3(sg.off[sg.n]), dim3(256), 0, (hipStream_t)stream, (const T*)src,
+                                       (T*)dst, sg, dim));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }
 
-extern "C" int fvqa_scatter_rows(const void* src, const int32_t* inv, void* dst, int src_rows, int dst_rows, int dim, int dtype,
-                                 void* stream) {
-  if (!src || !inv || !dst) return FVQA_EINVAL;
+extern "C" int fvqa_scatter_rows(const void* src, void* dst, const fvqa_row_segs* segs, int dim, int dtype, void* stream) {
+  if (!src || !dst) return FVQA_EINVAL;
   if (!fvqa_dtype_ok(dtype)) return FVQA_EINVAL;
+  RowSegs sg;
+  if (!segs_ok(segs, &sg)) return FVQA_EINVAL;
   const int e = 16 / (int)fvqa_dtype_size(dtype);
-  if (src_rows <= 0 || dst_rows <= 0 || dim <= 0 || dim % e) return FVQA_ESHAPE;
+  if (dim <= 0 || dim % e) return FVQA_ESHAPE;
   if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0) return FVQA_EALIGN;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(scatter_rows_k<T>, dim3(dst_rows), dim3(256), 0, (hipStream_t)stream, (const T*)src, inv,
-                                       (T*)dst, src_rows, dim));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(scatter_rows_k<T>, dim3(sg.n * sg.stream_rows), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)src, (T*)dst, sg, dim));
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;
 }

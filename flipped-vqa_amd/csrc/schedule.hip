@@ -77,6 +77,15 @@ int check_plan(const fvqa_layer_plan* p) {
       !p->cos_t || !p->sin_t || !p->vstart || !p->gemm_ws)
     return FVQA_EINVAL;
   if ((uintptr_t)p->gemm_ws & 255) return FVQA_EALIGN;
+  const auto& t = p->tail;
+  if (t.rows < 0) return FVQA_ESHAPE;
+  if (t.rows > 0) {                                   // the last layer's post-attention half on the gathered rows
+    if (t.gather.n < 1 || t.gather.n > 3 || t.gather.n != t.scatter.n || t.gather.stream_rows != t.scatter.stream_rows ||
+        t.gather.n * t.gather.stream_rows != p->n_seq * p->seq_len || t.gather.off[t.gather.n] != t.rows ||
+        t.scatter.off[t.scatter.n] != t.rows)
+      return FVQA_ESHAPE;
+    if (!t.og || !t.xg || !t.h || !t.hn || !t.ab || !t.z || !t.xl || !t.xnf || !t.rstd2 || !t.rstdN) return FVQA_EINVAL;
+  }
   return FVQA_OK;
 }
 
@@ -159,6 +168,25 @@ extern "C" int fvqa_layers_fwd(const fvqa_layer_plan* p, void* stream) {
                         p->max_feats, dt, stream));
     }
     }
+    if (i == L - 1 && p->tail.rows > 0) {
+      // The LAST layer's post-attention half and the final norm on the rows a head reads (include/fvqa.h "tail rows"): nothing
+      // else consumes this layer's output, so WO + residual, the FFN and the norm run on the gathered rows of o and x only.
+      const auto& t = p->tail;
+      const int M = t.rows;
+      RUN(fvqa_gather_rows(o, t.og, &t.gather, D, dt, stream));
+      RUN(fvqa_gather_rows(x, t.xg, &t.gather, D, dt, stream));
+      RUN(fvqa_gemm_nt(t.og, p->wo[i], t.h, t.xg, nullptr, M, D, D, D, D, D, M, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
+                       p->gemm_ws_bytes, stream));
+      RUN(fvqa_rmsnorm_fwd(t.h, p->fn[i], t.hn, t.rstd2, M, D, p->eps, dt, stream));
+      if (swiglu_st())
+        RUN(fvqa_gemm_nt_swiglu_fwd_st(t.hn, p->w13[i], t.ab, t.z, M, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
+      else
+        RUN(fvqa_gemm_nt_swiglu_fwd(t.hn, p->w13[i], t.ab, t.z, M, Hf, D, D, D, dt, p->gemm_ws, p->gemm_ws_bytes, stream));
+      RUN(fvqa_gemm_nt(t.z, p->w2[i], t.xl, t.h, nullptr, M, D, Hf, Hf, Hf, D, M, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
+                       p->gemm_ws_bytes, stream));
+      RUN(fvqa_rmsnorm_fwd(t.xl, p->norm_w, t.xnf, t.rstdN, M, D, p->eps, dt, stream));
+      break;
+    }
     // h = x + o·Wo^T (model.py:185), hn = RMSNorm(h)·w
     RUN(fvqa_gemm_nt(o, p->wo[i], h, x, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_RESIDUAL, 0, p->gemm_ws,
                      p->gemm_ws_bytes, stream));
@@ -200,7 +228,14 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
   const bool fused_rope = fvqa_attn_rope_fused(dt) != 0;
   const bool rope_gemm = fvqa_rope_in_gemm(dt) != 0;
   const int epi_sw = swiglu_st() ? FVQA_EPI_SWIGLU_BWD_ST : FVQA_EPI_SWIGLU_BWD;
-  RUN(fvqa_rmsnorm_bwd(dxnf, at(p->xs, (size_t)L * R * D, es), p->norm_w, p->rstdN, nullptr, cur, R, D, dt, stream));
+  const bool tail = p->tail.rows > 0;
+  if (tail) {
+    const auto& t = p->tail;
+    if (!t.dcur || !t.dab || !t.dt || !t.dh || !t.d_o) return FVQA_EINVAL;
+    RUN(fvqa_rmsnorm_bwd(dxnf, t.xl, p->norm_w, t.rstdN, nullptr, t.dcur, t.rows, D, dt, stream));      // dxnf: (rows, D)
+  } else {
+    RUN(fvqa_rmsnorm_bwd(dxnf, at(p->xs, (size_t)L * R * D, es), p->norm_w, p->rstdN, nullptr, cur, R, D, dt, stream));
+  }
   for (int i = L - 1; i >= 0; --i) {
     const void* x = at(p->xs, (size_t)i * R * D, es);
     const void* qkv = at(p->qkv, (size_t)i * Ra * 3 * D, es);
@@ -211,6 +246,21 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     const float* lse_t = p->lse_t + (size_t)i * n_seq * H * S;
     // dz = cur·W2 never reaches HBM: the SwiGLU backward is this GEMM's epilogue. On its idle CUs: the adapter-query
     // gradient rows of the layer walked just before (dqkv still holds that layer's [0, dK_a, dV_a] rows)
+    if (i == L - 1 && tail) {
+      // the compact half of the last layer, backwards: FFN', norm', WO^T on the tail rows; their d_o and dh rows are then
+      // scattered under the zero rows of everything else and the walk continues dense (attention' needs every key's row)
+      const auto& tr = p->tail;
+      const int M = tr.rows;
+      RUN(fvqa_gemm_nt(tr.dcur, p->w2_t[i], tr.dab, tr.ab, nullptr, M, Hf, D, D, D, 2 * Hf, M, dt, dt, epi_sw, 0,
+                       p->gemm_ws, p->gemm_ws_bytes, stream));
+      RUN(fvqa_gemm_nt(tr.dab, p->w13_t[i], tr.dt, nullptr, nullptr, M, D, 2 * Hf, 2 * Hf, 2 * Hf, D, M, dt, dt,
+                       FVQA_EPI_NONE, 0, p->gemm_ws, p->gemm_ws_bytes, stream));
+      RUN(fvqa_rmsnorm_bwd(tr.dt, tr.h, p->fn[i], tr.rstd2, tr.dcur, tr.dh, M, D, dt, stream));
+      RUN(fvqa_gemm_nt(tr.dh, p->wo_t[i], tr.d_o, nullptr, nullptr, M, D, D, D, D, D, M, dt, dt, FVQA_EPI_NONE, 0,
+                       p->gemm_ws, p->gemm_ws_bytes, stream));
+      RUN(fvqa_scatter_rows(tr.d_o, p->d_o, &tr.scatter, D, dt, stream));
+      RUN(fvqa_scatter_rows(tr.dh, p->dh, &tr.scatter, D, dt, stream));
+    } else {
     if (i + 1 < L) {
       const fvqa_sk_rider ga = adapter_grad_rider(p, i + 1);
       RUN(fvqa_gemm_nt_rider(cur, p->w2_t[i], p->dab, ab, R, Hf, D, D, D, 2 * Hf, dt, dt, epi_sw, &ga,
@@ -224,6 +274,7 @@ extern "C" int fvqa_layers_bwd(const fvqa_layer_plan* p, const void* dxnf, void*
     RUN(fvqa_rmsnorm_bwd(t, h, p->fn[i], p->rstd2 + (size_t)i * R, cur, p->dh, R, D, dt, stream));
     RUN(fvqa_gemm_nt(p->dh, p->wo_t[i], p->d_o, nullptr, nullptr, R, D, D, D, D, D, R, dt, dt, FVQA_EPI_NONE, 0,
                      p->gemm_ws, p->gemm_ws_bytes, stream));
+    }
     if (rope_gemm) {
       RUN(fvqa_attn_bwd_rotated(p->d_o, qkv, o, lse_a, lse_t, p->gate1[i], p->gate2[i], p->vstart, p->cos_t, p->sin_t,
                                 p->dqkv, p->dgate1[i], p->dgate2[i], p->attn_ws, p->attn_ws_bytes, n_seq, S, H, Dh, A,

@@ -7,5 +7,5 @@
 #define FVQA_SOURCE_HASH "unknown"
 #endif
 
-extern "C" int fvqa_version(void) { return 15; }
+extern "C" int fvqa_version(void) { return 16; }
 extern "C" const char* fvqa_source_hash(void) { return FVQA_SOURCE_HASH; }

@@ -12,7 +12,7 @@ from typing import Optional
 
 F32, BF16, F16 = 0, 1, 2
 EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU_BWD, EPI_SWIGLU_BWD_ST = 0, 1, 3, 6
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _p, _i, _f, _i64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 
@@ -61,8 +61,8 @@ SIGNATURES = {
     "fvqa_adamw_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _p, _p]),
     "fvqa_scaler_update": (_i, [_p, _p, _p, _p, _f, _f, _i, _p]),
     "fvqa_cast_rows": (_i, [_p, _p, _i, _i, _i, _p]),
-    "fvqa_gather_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
-    "fvqa_scatter_rows": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "fvqa_gather_rows": (_i, [_p, _p, _p, _i, _i, _p]),
+    "fvqa_scatter_rows": (_i, [_p, _p, _p, _i, _i, _p]),
     "fvqa_layers_gemm_workspace": (_sz, [_p]),
     "fvqa_layers_fwd": (_i, [_p, _p]),
     "fvqa_layers_bwd": (_i, [_p, _p, _p, _p]),
@@ -82,6 +82,18 @@ class SkRope(C.Structure):
     _fields_ = [("cos_t", C.c_void_p), ("sin_t", C.c_void_p)] + [(n, C.c_int32) for n in ("seq_len", "head_dim", "cols")]
 
 
+class RowSegs(C.Structure):
+    """Mirror of `fvqa_row_segs` (include/fvqa.h)."""
+    _fields_ = [("n", C.c_int32), ("stream_rows", C.c_int32), ("off", C.c_int32 * 4), ("map", C.c_void_p * 3)]
+
+
+class TailRows(C.Structure):
+    """Mirror of `struct fvqa_tail_rows` inside `fvqa_layer_plan`."""
+    _fields_ = ([("rows", C.c_int32), ("reserved_", C.c_int32), ("gather", RowSegs), ("scatter", RowSegs)]
+                + [(n, C.c_void_p) for n in ("og", "xg", "h", "hn", "ab", "z", "xl", "xnf", "rstd2", "rstdN",
+                                             "dcur", "dab", "dt", "dh", "d_o")])
+
+
 class LayerPlan(C.Structure):
     """Mirror of `fvqa_layer_plan` (include/fvqa.h) — field order and types must match exactly."""
     _fields_ = (
@@ -93,7 +105,7 @@ class LayerPlan(C.Structure):
         + [(n, C.c_void_p) for n in ("adapter", "adapter_c", "d_adapter", "norm_w", "xs", "rstd1", "rstd2", "qkv", "o", "lse_a",
                                      "lse_t", "h", "ab", "xn", "hn", "z", "xnf", "rstdN", "cos_t", "sin_t",
                                      "vstart", "dcur", "dnxt", "dz", "dab", "dh", "d_o", "dqkv", "attn_ws")]
-        + [("attn_ws_bytes", C.c_size_t), ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t)]
+        + [("attn_ws_bytes", C.c_size_t), ("gemm_ws", C.c_void_p), ("gemm_ws_bytes", C.c_size_t), ("tail", TailRows)]
     )
 
 

@@ -390,24 +390,41 @@ def swiglu_bwd(dz, ab, dab, rows: int, hidden: int):
     return dab
 
 
-def gather_rows(src, idx, dst):
-    """dst (n, dim) row j <- src row idx[j] (int32 device indices; an index outside src gives a zero row)."""
-    _dev(src, idx, dst)
+def row_segs(maps, offs, stream_rows: int):
+    """fvqa_row_segs (include/fvqa.h) of up to three streams: maps[k] the int32 device map of stream k (gather: compact -> dense row
+    within the stream; scatter: dense row -> compact row within the segment, -1 none), offs the segment offsets (len(maps) + 1)."""
+    n = len(maps)
+    _need(1 <= n <= 3 and len(offs) == n + 1 and offs[0] == 0, "row_segs: 1..3 segments starting at 0")
+    sg = _lib.RowSegs()
+    sg.n, sg.stream_rows = n, int(stream_rows)
+    for k in range(4):
+        sg.off[k] = int(offs[min(k, n)])
+    for k, m in enumerate(maps):
+        _dev(m)
+        _need(m.dtype == torch.int32 and m.dim() == 1 and m.is_contiguous(), "row_segs: int32 maps")
+        sg.map[k] = m.data_ptr()
+    sg._keep = list(maps)
+    return sg
+
+
+def gather_rows(src, dst, segs):
+    """dst (M, dim) compact <- rows of src ((n * stream_rows), dim) dense, by segs (row_segs of idx maps)."""
+    import ctypes as C
+    _dev(src, dst)
     _need(src.dim() == 2 and dst.dim() == 2 and src.dtype == dst.dtype and src.shape[1] == dst.shape[1], "gather_rows: shape")
-    _need(idx.dtype == torch.int32 and idx.dim() == 1 and idx.numel() == dst.shape[0], "gather_rows: idx")
-    rc = _lib.load(src.dtype).fvqa_gather_rows(_ptr(src), _ptr(idx), _ptr(dst), src.shape[0], dst.shape[0], src.shape[1],
-                                               dt_code(src.dtype), _stream())
+    _need(src.shape[0] >= segs.n * segs.stream_rows and dst.shape[0] >= segs.off[segs.n], "gather_rows: rows")
+    rc = _lib.load(src.dtype).fvqa_gather_rows(_ptr(src), _ptr(dst), C.addressof(segs), src.shape[1], dt_code(src.dtype), _stream())
     _lib.check(rc, "fvqa_gather_rows")
     return dst
 
 
-def scatter_rows(src, inv, dst):
-    """dst (rows, dim) row r <- src row inv[r], zeros where inv[r] < 0 (int32 device array, one entry per dst row)."""
-    _dev(src, inv, dst)
+def scatter_rows(src, dst, segs):
+    """dst ((n * stream_rows), dim) dense <- rows of src (M, dim) compact by segs (row_segs of inv maps), zeros where the map is < 0."""
+    import ctypes as C
+    _dev(src, dst)
     _need(src.dim() == 2 and dst.dim() == 2 and src.dtype == dst.dtype and src.shape[1] == dst.shape[1], "scatter_rows: shape")
-    _need(inv.dtype == torch.int32 and inv.dim() == 1 and inv.numel() == dst.shape[0], "scatter_rows: inv")
-    rc = _lib.load(src.dtype).fvqa_scatter_rows(_ptr(src), _ptr(inv), _ptr(dst), src.shape[0], dst.shape[0], src.shape[1],
-                                                dt_code(src.dtype), _stream())
+    _need(dst.shape[0] >= segs.n * segs.stream_rows and src.shape[0] >= segs.off[segs.n], "scatter_rows: rows")
+    rc = _lib.load(src.dtype).fvqa_scatter_rows(_ptr(src), _ptr(dst), C.addressof(segs), src.shape[1], dt_code(src.dtype), _stream())
     _lib.check(rc, "fvqa_scatter_rows")
     return dst
 

@@ -24,29 +24,42 @@ import torch
 from . import _lib, ops, scored
 
 TASKS = ("vqa", "vaq", "qav")
-class ScoredRows:
-    """The scored-row lists (fvqa/scored.py) of the LM streams one engine runs, on its device, with the segments of the compact
-    layout: stream k's rows sit at [offset_k, offset_k + rows_k) of the gathered matrix."""
+class TailRows:
+    """The rows a head reads (fvqa/scored.py), for the streams one engine runs, on its device: segment k of the compact layout =
+    stream k's rows, [off_k, off_k + rows_k). LM streams come first (vqa [, vaq]), then qav. `gather` / `scatter` are the
+    fvqa_row_segs of the idx / inv maps over ALL streams; `lab[k]` the shifted labels of LM segment k."""
 
-    def __init__(self, batch: dict, lm_tasks, device):
-        self.idx, self.inv, self.lab, self.segs, self.counts = [], [], [], [], []
-        off = 0
-        for t in lm_tasks:
+    def __init__(self, batch: dict, tasks, device, stream_rows: int):
+        idx, inv, offs = [], [], [0]
+        self.lab, self.segs, self.counts = [], [], []
+        mv = lambda x: x if x.device == device else x.to(device, non_blocking=True)        # noqa: E731
+        for t in tasks:
             m = int(batch[scored.COUNT][t])
             rows = scored.rows_of(m)
-            mv = lambda x: x if x.device == device else x.to(device, non_blocking=True)        # noqa: E731
-            self.idx.append(mv(batch["scored_idx"][t]).reshape(-1)[:rows])
-            self.inv.append(mv(batch["scored_inv"][t]).reshape(-1))
-            self.lab.append(mv(batch["scored_lab"][t]).reshape(-1)[:rows])
-            self.segs.append((off, rows))
+            idx.append(mv(batch["scored_idx"][t]).reshape(-1)[:rows])
+            inv.append(mv(batch["scored_inv"][t]).reshape(-1))
+            if t in scored.LM_TASKS:
+                self.lab.append(mv(batch["scored_lab"][t]).reshape(-1)[:rows])
+            self.segs.append((offs[-1], rows))
             self.counts.append(m)
-            off += rows
-        self.M = off
+            offs.append(offs[-1] + rows)
+        self.tasks = tuple(tasks)
+        self.idx, self.inv = idx, inv
+        self.M = offs[-1]
+        self.n_lm = sum(1 for t in tasks if t in scored.LM_TASKS)
+        self.M_lm = offs[self.n_lm]                                  # LM segments are the first rows of the compact matrix
+        self.gather = ops.row_segs(idx, offs, stream_rows)
+        self.scatter = ops.row_segs(inv, offs, stream_rows)
+
+    def one(self, k: int, stream_rows: int):
+        """(gather, scatter) segs of stream k alone, against a compact matrix that starts at its segment."""
+        rows = self.segs[k][1]
+        return ops.row_segs([self.idx[k]], [0, rows], stream_rows), ops.row_segs([self.inv[k]], [0, rows], stream_rows)
 
 
 def stage_batch(data: dict, device) -> dict:
     """A batch dict (dataloader/__init__.py:28-90 schema, host tensors) moved to `device` for a resident-batch loop, the
-    scored-row lists of its LM streams (fvqa/scored.py) taken while the labels are on the host and moved with the rest."""
+    tail-row lists of its streams (fvqa/scored.py) taken while the labels are on the host and moved with the rest."""
     out = scored.annotate({k: (dict(v) if isinstance(v, dict) else v) for k, v in data.items()})
     out["video"] = out["video"].to(device)
     for k in ("text_id", "label", "video_index") + scored.FIELDS:
@@ -161,12 +174,15 @@ class Arena:
             self._dlogits = self._e(self.n_lm * self.S, self._V)
         return self._dlogits
 
-    def compact(self, M: int, D: int):
-        """Buffers of the scored-rows head for M compact rows (gathered inputs, logits, their gradients)."""
+    def compact(self, M: int, D: int, Hf: int):
+        """Buffers of the tail rows for M compact rows: the last layer's post-attention half, the LM head, their backward."""
         if M > self._compact_cap:
             cap = (M + 63) // 64 * 64
             e, V, f32 = self._e, self._V, torch.float32
-            self.xg, self.dxg = e(cap, D), e(cap, D)
+            for n in ("og", "xg", "h_c", "hn_c", "xl_c", "xnf_c", "dxnf_c", "dcur_c", "dt_c", "dh_c", "do_c"):
+                setattr(self, n, e(cap, D))
+            self.ab_c, self.dab_c, self.z_c = e(cap, 2 * Hf), e(cap, 2 * Hf), e(cap, Hf)
+            self.rstd2_c, self.rstdN_c = e(cap, dtype=f32), e(cap, dtype=f32)
             self.logits_c, self.dlogits_c = e(cap, V, dtype=f32), e(cap, V)
             self.lse_c, self.rowloss_c = e(cap, dtype=f32), e(cap, dtype=f32)
             self._compact_cap = cap
@@ -312,7 +328,7 @@ class StepEngine:
         video_d = video.to(dev, dtype=torch.float32, non_blocking=True).reshape(B * F, -1).contiguous()
         # (with the other host-to-device copies of the batch, not behind the layers: a pageable copy holds the host until the
         # stream reaches it)
-        sc = self._scored(data) if self.lm_head_rows == "scored" else None
+        tl = self._tail(data, B, S) if self.lm_head_rows == "scored" else None
         qidx = None
         if "qav" in self.tasks:
             qi = data["video_index"]["qav"]
@@ -338,52 +354,70 @@ class StepEngine:
             else:
                 ops.embed_splice(ids[t], pk.emb, vf_tok, h0, B, S, F, vstart=vs[t], mode=0)
 
+        if tl is not None:
+            ar.compact(tl.M, D, Hf)
         if self.use_native_schedule():
             plan = self.layer_plan(ar, m._flat, vstart)
+            self._plan_tail(plan, ar, tl)
             _lib.check(_lib.load(self.dtype).fvqa_layers_fwd(C.addressof(plan), torch.cuda.current_stream().cuda_stream),
                        "fvqa_layers_fwd")
         else:
-            self._layers_fwd_py(ar, vstart, n_seq, S)
+            self._layers_fwd_py(ar, vstart, n_seq, S, tl)
         n_lm = ar.n_lm
         ar.loss_sum.zero_()
-        if sc is not None:
-            # LM head on the scored rows only: gather per stream -> (M, D) x W_out^T -> CE per stream segment (one "sequence" each)
-            ar.compact(sc.M, D)
-            xg, lg = ar.xg[: sc.M], ar.logits_c[: sc.M]
-            for k, (o0, rows_k) in enumerate(sc.segs):
-                ops.gather_rows(ar.xnf[k * B * S:(k + 1) * B * S], sc.idx[k], xg[o0:o0 + rows_k])
-            ops.gemm_nt(xg, pk.wout, lg)
-            for k, (o0, rows_k) in enumerate(sc.segs):
+        if tl is not None:
+            # the layers left the final-norm output of the tail rows in ar.xnf_c: LM segments first -> (M_lm, D) x W_out^T -> CE per
+            # stream segment (one "sequence" each)
+            lg = ar.logits_c[: tl.M_lm]
+            ops.gemm_nt(ar.xnf_c[: tl.M_lm], pk.wout, lg)
+            for k in range(tl.n_lm):
+                o0, rows_k = tl.segs[k]
                 seg = slice(o0, o0 + rows_k)
-                ops.ce_fwd(lg[seg], sc.lab[k], ar.lse_c[seg], ar.rowloss_c[seg], ar.loss_sum[k], 1, rows_k, V, 0)
+                ops.ce_fwd(lg[seg], tl.lab[k], ar.lse_c[seg], ar.rowloss_c[seg], ar.loss_sum[k], 1, rows_k, V, 0)
         else:
             ops.gemm_nt(ar.xnf[: n_lm * S], pk.wout, ar.logits)
         for k, t in enumerate(self.tasks):
             rows = slice(k * B * S, (k + 1) * B * S)
             if t == "qav":
+                if tl is not None:      # the QAV head's kernels read dense rows (and skip the ones it ignores): its segment goes back
+                    o0, rows_k = tl.segs[k]
+                    ops.scatter_rows(ar.xnf_c[o0:o0 + rows_k], ar.xnf[rows], tl.one(k, B * S)[1])
                 ops.qav_head_fwd(ar.xnf[rows], vf_raw, labels[t], ar.probs[k * B * S * F:], ar.rowloss[rows],
                                  ar.loss_sum[2], B, S, D, F, self.tau)
-            elif sc is None:
+            elif tl is None:
                 ops.ce_fwd(ar.logits[rows], labels[t], ar.lse[rows], ar.rowloss[rows], ar.loss_sum[k], B, S, V, 0)
         self.saved = dict(ar=ar, B=B, S=S, vs=vs, labels=labels, qidx=qidx, video=video_d, vf_raw=vf_raw,
-                          vstart=vstart, scored=sc)
-        self.last_scored = sc                                   # (tests: which rows the compact logits belong to)
+                          vstart=vstart, tail=tl)
+        self.last_scored = tl                                   # (tests: which rows the compact results belong to)
         losses = ar.loss_sum[:, 0] / ar.loss_sum[:, 1]        # mean over scored rows (NaN if none, as torch CE)
         return losses
 
-    def _scored(self, data: dict) -> Optional[ScoredRows]:
-        """The batch's scored-row lists on the device. They come with the batch (the batch producer and stage_batch make them
-        where the labels are on the host) or are made here from host labels; None — the dense head — for device labels without
+    def _tail(self, data: dict, B: int, S: int) -> Optional[TailRows]:
+        """The batch's tail-row lists on the device. They come with the batch (the batch producer and stage_batch make them
+        where the labels are on the host) or are made here from host labels; None — the dense form — for device labels without
         lists: reading them back would stall the step."""
-        lm = tuple(t for t in self.tasks if t in scored.LM_TASKS)
         have = data.get(scored.COUNT, {})
-        if not all(t in have for t in lm):
-            if any(data["label"][t].is_cuda for t in lm):
+        if not all(t in have for t in self.tasks):
+            if any(data["label"][t].is_cuda for t in self.tasks):
                 return None
-            data = scored.annotate({"label": {t: data["label"][t] for t in lm}})
-        return ScoredRows(data, lm, self.device)
+            data = scored.annotate({"label": {t: data["label"][t] for t in self.tasks}})
+        return TailRows(data, self.tasks, self.device, B * S)
 
-    def _layers_fwd_py(self, ar, vstart, n_seq, S):
+    def _plan_tail(self, plan, ar: "Arena", tl: Optional[TailRows]):
+        """fvqa_layer_plan.tail for this step (rows = 0: dense)."""
+        t = plan.tail
+        if tl is None:
+            t.rows = 0
+            return
+        t.rows = tl.M
+        C.memmove(C.addressof(t.gather), C.addressof(tl.gather), C.sizeof(_lib.RowSegs))
+        C.memmove(C.addressof(t.scatter), C.addressof(tl.scatter), C.sizeof(_lib.RowSegs))
+        for f, n in (("og", "og"), ("xg", "xg"), ("h", "h_c"), ("hn", "hn_c"), ("ab", "ab_c"), ("z", "z_c"), ("xl", "xl_c"),
+                     ("xnf", "xnf_c"), ("rstd2", "rstd2_c"), ("rstdN", "rstdN_c"), ("dcur", "dcur_c"), ("dab", "dab_c"),
+                     ("dt", "dt_c"), ("dh", "dh_c"), ("d_o", "do_c")):
+            setattr(t, f, getattr(ar, n).data_ptr())
+
+    def _layers_fwd_py(self, ar, vstart, n_seq, S, tl=None):
         """The same layer walk as csrc/schedule.hip, one ctypes call per kernel."""
         m, pk = self.model, self.pack
         F, D, A, H, Dh, Hf, L = self.F, self.D, self.A, self.H, self.Dh, self.Hf, self.L
@@ -413,6 +447,17 @@ class StepEngine:
                 else:
                     ops.rope_qk(ar.qkv[i], self.cos, self.sin, n_seq, S, H, Dh)
                     ops.attn_fwd(ar.qkv[i], ar.o[i], ar.lse_a[i], ar.lse_t[i], g1, g2, vstart, n_seq, S, H, Dh, A, F)
+            if tl is not None and i == L - 1:
+                # the last layer's post-attention half and the final norm on the tail rows only (csrc/schedule.hip, same calls)
+                M = tl.M
+                ops.gather_rows(ar.o[i], ar.og[:M], tl.gather)
+                ops.gather_rows(x, ar.xg[:M], tl.gather)
+                ops.gemm_nt(ar.og[:M], pk.wo[i], ar.h_c[:M], residual=ar.xg[:M])
+                ops.rmsnorm_fwd(ar.h_c[:M], pk.fn[i], ar.hn_c[:M], ar.rstd2_c[:M], self.eps, rows=M)
+                ops.gemm_nt_swiglu_fwd(ar.hn_c[:M], pk.w13[i], ar.ab_c[:M], ar.z_c[:M], st=st)
+                ops.gemm_nt(ar.z_c[:M], pk.w2[i], ar.xl_c[:M], residual=ar.h_c[:M])
+                ops.rmsnorm_fwd(ar.xl_c[:M], pk.norm, ar.xnf_c[:M], ar.rstdN_c[:M], self.eps, rows=M)
+                break
             ops.gemm_nt(ar.o[i], pk.wo[i], ar.h[i], residual=x)           # h = x + o·Wo^T
             ops.rmsnorm_fwd(ar.h[i], pk.fn[i], ar.hn, ar.rstd2[i], self.eps, rows=R)
             if kv_ahead and i + 1 < L:      # z = silu(a)*b; ab[i] <- (s, t); rider: the next layer's adapter K/V rows
@@ -445,34 +490,39 @@ class StepEngine:
         has_qav = "qav" in self.tasks
         if has_qav:
             ar.d_qav.zero_()
-        sc = sv.get("scored")
+        tl = sv.get("tail")
         for k, t in enumerate(self.tasks):
             rows = slice(k * B * S, (k + 1) * B * S)
             if t == "qav":
                 ops.qav_head_bwd(ar.xnf[rows], sv["vf_raw"], labels[t], ar.probs[k * B * S * F:], ar.loss_sum[2],
                                  ar.gscale[2:3], ar.dxnf[rows], ar.d_qav, B, S, D, F, self.tau)
-            elif sc is None:
+                if tl is not None:      # its gradient rows join the compact matrix
+                    o0, rows_k = tl.segs[k]
+                    ops.gather_rows(ar.dxnf[rows], ar.dxnf_c[o0:o0 + rows_k], tl.one(k, B * S)[0])
+            elif tl is None:
                 ops.ce_bwd(ar.logits[rows], labels[t], ar.lse[rows], ar.loss_sum[k], ar.gscale[k:k + 1],
                            ar.dlogits[rows], B, S, V, 0)
-        if sc is not None:
-            # d(logits) of the scored rows -> their dX rows through W_out -> scattered under the zero rows of everything else
-            lg, dlg, dxg = ar.logits_c[: sc.M], ar.dlogits_c[: sc.M], ar.dxg[: sc.M]
-            for k, (o0, rows_k) in enumerate(sc.segs):
+        if tl is not None:
+            # d(logits) of the scored rows -> their dX rows through W_out, straight into the compact gradient of the final norm
+            lg, dlg = ar.logits_c[: tl.M_lm], ar.dlogits_c[: tl.M_lm]
+            for k in range(tl.n_lm):
+                o0, rows_k = tl.segs[k]
                 seg = slice(o0, o0 + rows_k)
-                ops.ce_bwd(lg[seg], sc.lab[k], ar.lse_c[seg], ar.loss_sum[k], ar.gscale[k:k + 1], dlg[seg], 1, rows_k, V, 0)
-            ops.gemm_nt(dlg, pk.wout_t, dxg)
-            for k, (o0, rows_k) in enumerate(sc.segs):
-                ops.scatter_rows(dxg[o0:o0 + rows_k], sc.inv[k], ar.dxnf[k * B * S:(k + 1) * B * S])
+                ops.ce_bwd(lg[seg], tl.lab[k], ar.lse_c[seg], ar.loss_sum[k], ar.gscale[k:k + 1], dlg[seg], 1, rows_k, V, 0)
+            ops.gemm_nt(dlg, pk.wout_t, ar.dxnf_c[: tl.M_lm])
+            dxnf = ar.dxnf_c
         else:
             ops.gemm_nt(ar.dlogits, pk.wout_t, ar.dxnf[: ar.n_lm * S])
+            dxnf = ar.dxnf
         if self.use_native_schedule():
             plan = self.layer_plan(ar, grads, sv["vstart"])
+            self._plan_tail(plan, ar, tl)
             out = C.c_void_p()
-            _lib.check(_lib.load(self.dtype).fvqa_layers_bwd(C.addressof(plan), ar.dxnf.data_ptr(), C.addressof(out),
+            _lib.check(_lib.load(self.dtype).fvqa_layers_bwd(C.addressof(plan), dxnf.data_ptr(), C.addressof(out),
                                                    torch.cuda.current_stream().cuda_stream), "fvqa_layers_bwd")
             cur = ar.da if out.value == ar.da.data_ptr() else ar.db
         else:
-            cur = self._layers_bwd_py(ar, grads, sv, n_seq, S)
+            cur = self._layers_bwd_py(ar, grads, sv, n_seq, S, tl)
         for k, t in enumerate(self.tasks):
             dh0 = cur[k * B * S:(k + 1) * B * S]
             if t == "qav":
@@ -484,24 +534,37 @@ class StepEngine:
         self.saved = None
 
 
-    def _layers_bwd_py(self, ar, grads, sv, n_seq, S):
+    def _layers_bwd_py(self, ar, grads, sv, n_seq, S, tl=None):
         m, pk = self.model, self.pack
         F, D, A, H, Dh, Hf, L = self.F, self.D, self.A, self.H, self.Dh, self.Hf, self.L
         R = ar.R
         cur, nxt = ar.da, ar.db
         t = ar.dz.view(-1)[: R * D].view(R, D)
-        ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
+        if tl is not None:
+            M = tl.M
+            ops.rmsnorm_bwd(ar.dxnf_c[:M], ar.xl_c[:M], pk.norm, ar.rstdN_c[:M], ar.dcur_c[:M], rows=M)
+        else:
+            ops.rmsnorm_bwd(ar.dxnf, ar.xs[L], pk.norm, ar.rstdN, cur, rows=R)
         g_adapter = grads.grad_view("adapter_query.weight").view(-1, A, D)
         st = ops.swiglu_st()                 # (FVQA_SWIGLU_AB=1 switches BOTH schedules to the a, b form)
         for i in reversed(range(L)):
-            if i + 1 < L:                    # dz·SwiGLU' in the epilogue; rider: the previous layer's adapter-grad rows
-                ops.gemm_nt_rider(cur, pk.w2_t[i], ar.dab, swiglu_ab=ar.ab[i], swiglu_st=st, rider_a=ar.dqkv[R:, D:],
-                                  rider_b=pk.wqkv_t[i + 1][:, D:], rider_out=g_adapter[i + 1], accumulate=True)
+            if tl is not None and i == L - 1:
+                M = tl.M
+                ops.gemm_nt_swiglu_bwd(ar.dcur_c[:M], pk.w2_t[i], ar.ab_c[:M], ar.dab_c[:M], st=st)
+                ops.gemm_nt(ar.dab_c[:M], pk.w13_t[i], ar.dt_c[:M])
+                ops.rmsnorm_bwd(ar.dt_c[:M], ar.h_c[:M], pk.fn[i], ar.rstd2_c[:M], ar.dh_c[:M], resid=ar.dcur_c[:M], rows=M)
+                ops.gemm_nt(ar.dh_c[:M], pk.wo_t[i], ar.do_c[:M])
+                ops.scatter_rows(ar.do_c[:M], ar.do, tl.scatter)
+                ops.scatter_rows(ar.dh_c[:M], ar.dh, tl.scatter)
             else:
-                ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab, st=st)
-            ops.gemm_nt(ar.dab, pk.w13_t[i], t)
-            ops.rmsnorm_bwd(t, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
-            ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)
+                if i + 1 < L:                    # dz·SwiGLU' in the epilogue; rider: the previous layer's adapter-grad rows
+                    ops.gemm_nt_rider(cur, pk.w2_t[i], ar.dab, swiglu_ab=ar.ab[i], swiglu_st=st, rider_a=ar.dqkv[R:, D:],
+                                      rider_b=pk.wqkv_t[i + 1][:, D:], rider_out=g_adapter[i + 1], accumulate=True)
+                else:
+                    ops.gemm_nt_swiglu_bwd(cur, pk.w2_t[i], ar.ab[i], ar.dab, st=st)
+                ops.gemm_nt(ar.dab, pk.w13_t[i], t)
+                ops.rmsnorm_bwd(t, ar.h[i], pk.fn[i], ar.rstd2[i], ar.dh, resid=cur, rows=R)
+                ops.gemm_nt(ar.dh, pk.wo_t[i], ar.do)
             g1, g2 = m.gate_views(i)
             dg1, dg2 = grads.gate_grad_views(i)
             if ops.attn_rope_fused(self.dtype):

@@ -73,8 +73,7 @@ const char* fvqa_arch(void); /* "gfx950"                                     */
  * tail[(m - m_split)*N + n] (ACCUMULATED, +=) instead of C (adapter-query gradient rows).
  * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows.
  * variant 0 picks the kernel: the persistent 256x256-tile LDS-DMA ring kernel (M >= 192, N >= 256, N % 8 == 0, no
- * tail rows, workspace given; also 16 < M < 192 against >= 100 M weights: the LM head and its dX on the scored rows of a
- * batch, llama/model.py:348-350), the weight-streaming kernel of the generation path for bf16 M <= 16, K % 256 == 0 (one
+ * tail rows, workspace given; also 16 < M < 192 against >= 16 M weights: the projections of the tail rows, see fvqa_row_segs), the weight-streaming kernel of the generation path for bf16 M <= 16, K % 256 == 0 (one
  * new token per sequence, llama/model.py:439-447 run row-wise; with C == NULL, m_split == 0 it accumulates every row
  * into `tail`: the adapter-query gradient rows), else the 128x128-tile kernel. Other variant codes force a kernel
  * (1 / 2 = 128x128 register- / DMA-staged, 12 = weight-streaming, 13 = persistent; tests, tuning). */
@@ -340,6 +339,26 @@ int fvqa_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
 int fvqa_scaler_update(float* step, float* scale, float* growth_tracker, const float* found_inf,
                        float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
+/* ---- the rows a head reads ("tail rows") -----------------------------------------------------
+ * The reference evaluates `output` at every position and lets the cross-entropy ignore the rows whose next label is 0
+ * (llama/model.py:348-350); the QAV head likewise reads the frame-token rows only (:359-361). A row no head
+ * reads contributes neither to a loss nor to any gradient — and in the LAST layer nothing else reads its output either. The
+ * step therefore runs the last layer's post-attention half (WO + residual, FFN, final norm), the heads and all of their
+ * backward on the tail rows only, gathered into a compact matrix; results are those of the dense form.
+ * Row movers: a compact matrix of segs->off[n] rows against n streams of `stream_rows` dense rows each.
+ *   gather : compact row off[k] + j  <- dense row k*stream_rows + map[k][j]      (an index outside the stream: a zero row)
+ *   scatter: dense row k*stream_rows + r <- compact row off[k] + map[k][r], zeros where map[k][r] < 0 (every dense row of
+ *            the n streams written exactly once: no pre-clear, no atomics)
+ * map[k]: int32 device arrays (gather: off[k+1]-off[k] entries; scatter: stream_rows entries); rows 16-byte aligned,
+ * dim a multiple of 16 bytes. */
+typedef struct fvqa_row_segs {
+  int32_t n, stream_rows;
+  int32_t off[4];
+  const int32_t* map[3];
+} fvqa_row_segs;
+int fvqa_gather_rows(const void* src, void* dst, const fvqa_row_segs* segs, int dim, int dtype, void* stream);
+int fvqa_scatter_rows(const void* src, void* dst, const fvqa_row_segs* segs, int dim, int dtype, void* stream);
+
 /* ---- native layer schedule (csrc/schedule.hip): the L transformer blocks of the step walked in
  * C++ — two calls per step instead of ~700 per-kernel calls from the host language. Every pointer
  * is a device pointer except the per-layer tables (host arrays of n_layers device pointers).
@@ -399,6 +418,16 @@ typedef struct fvqa_layer_plan {
   void* gemm_ws;             /* >= fvqa_layers_gemm_workspace(plan) bytes, 256-byte aligned, first 4096 bytes
                                 zeroed once after allocation (see fvqa_gemm_workspace) */
   size_t gemm_ws_bytes;
+  /* tail rows (fvqa_row_segs above; rows == 0: dense, nothing here is read). With rows > 0 fvqa_layers_fwd runs the
+   * last layer's post-attention half and the final norm on the gathered rows — xs[L], h[L-1], ab[L-1], rstd2[L-1], xnf and
+   * rstdN are NOT written; tail.xnf (rows, D) is the final-norm output — and fvqa_layers_bwd takes `dxnf` as (rows, D). */
+  struct fvqa_tail_rows {
+    int32_t rows, reserved_;
+    fvqa_row_segs gather, scatter;                  /* the same segments with the idx / inv maps */
+    void *og, *xg, *h, *hn, *ab, *z, *xl, *xnf;   /* (rows, D) except ab (rows, 2Hf), z (rows, Hf); saved for the backward: h, ab, xl */
+    float *rstd2, *rstdN;                           /* (rows) */
+    void *dcur, *dab, *dt, *dh, *d_o;               /* backward scratch: (rows, D) except dab (rows, 2Hf) */
+  } tail;
 } fvqa_layer_plan;
 
 /* bytes of GEMM workspace the projections of one layer (forward and backward) need at most */
@@ -413,18 +442,6 @@ int fvqa_layers_bwd(const fvqa_layer_plan* plan, const void* dxnf, void** d_x0, 
  * dst rows [row0, row0+n_rows) of a (.., dim) storage-dtype matrix <- fp32 src (n_rows, dim)
  * (adapter_query rows appended under the normed activations, llama/model.py:339) */
 int fvqa_cast_rows(const float* src, void* dst, int n_rows, int dim, int dtype, void* stream);
-
-/* ---- LM head on the scored rows only ---------------------------------------------------------
- * The reference evaluates `output` at every position and lets the cross-entropy ignore the rows whose next label is 0
- * (llama/model.py:348-350). A row that is ignored contributes neither to the loss nor to any gradient,
- * so the step gathers the scored rows of the final-norm output, runs the head and its dX on those (fvqa_gemm_nt), and
- * scatters the gradient rows back; results are those of the dense form.
- *   gather : dst (n_idx, dim) row j <- src row idx[j]            (an index outside [0, src_rows) gives a zero row)
- *   scatter: dst (dst_rows, dim) row r <- src row inv[r], zeros where inv[r] < 0 (every row written once; no pre-clear)
- * idx / inv: int32 device arrays; rows 16-byte aligned, dim a multiple of 16 bytes. */
-int fvqa_gather_rows(const void* src, const int32_t* idx, void* dst, int src_rows, int n_idx, int dim, int dtype, void* stream);
-int fvqa_scatter_rows(const void* src, const int32_t* inv, void* dst, int src_rows, int dst_rows, int dim, int dtype,
-                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,5 +79,12 @@ def run_step(model, batch, loss_weights=(1.0, 1.0, 1.0), lm_head="all"):
     layer_out = []
     for i in range(eng.L):
         for k, t in enumerate(eng.tasks):
-            layer_out.append(ar.xs[i + 1][k * B * S:(k + 1) * B * S].view(B, S, -1).float().cpu())
+            if sc is not None and i == eng.L - 1:
+                # tail-rows mode: the last layer's output exists for the rows a head reads only (NaN elsewhere)
+                o0, m = sc.segs[k][0], sc.counts[k]
+                full = torch.full((B * S, eng.D), float("nan"))
+                full[sc.idx[k][:m].long().cpu()] = ar.xl_c[o0:o0 + m].float().cpu()
+                layer_out.append(full.view(B, S, -1))
+            else:
+                layer_out.append(ar.xs[i + 1][k * B * S:(k + 1) * B * S].view(B, S, -1).float().cpu())
     return losses, grads, logits, layer_out

@@ -120,8 +120,16 @@ def compare_with_golden(g, losses, grads, logits=None, layer_out=None, *, rtol, 
         for i, t in enumerate(layer_out):
             f = t.detach().double().cpu().flatten()
             nrm = float(cs[i, 1])
-            e_norm = abs(float(f.norm()) - nrm) / nrm
             scale = nrm / np.sqrt(f.numel())
+            if scored_rows_only and bool(torch.isnan(f).any()):
+                # the last layer in tail-rows mode: only the rows a head reads exist — the golden's picks that fall on them
+                got = f[torch.from_numpy(pick[i])].numpy()
+                keep = ~np.isnan(got)
+                e_pick = float(np.abs(got[keep] - cs[i, 2:][keep]).max() / scale) if keep.any() else 0.0
+                worst = max(worst, e_pick)
+                assert e_pick <= 4 * t_layer, f"layer_out[{i}] (tail rows): pick {e_pick:.3e}"
+                continue
+            e_norm = abs(float(f.norm()) - nrm) / nrm
             e_pick = float(np.abs(f[torch.from_numpy(pick[i])].numpy() - cs[i, 2:]).max() / scale)
             worst = max(worst, e_norm, e_pick)
             assert e_norm <= t_layer and e_pick <= 4 * t_layer, f"layer_out[{i}]: norm {e_norm:.3e} pick {e_pick:.3e}"

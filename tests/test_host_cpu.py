@@ -422,13 +422,13 @@ def test_scored_rows_lists_match_the_cross_entropy_rule():
     batch["label"]["vqa"][1] = 0                              # a sample with no scored row
     batch["label"]["vaq"][0, 0, 7] = -3                       # a negative label is not a class id
     out = scored.annotate(batch)
-    assert out is batch and set(batch[scored.COUNT]) == {"vqa", "vaq"}
-    for t in ("vqa", "vaq"):
+    assert out is batch and set(batch[scored.COUNT]) == {"vqa", "vaq", "qav"}
+    for t in ("vqa", "vaq", "qav"):
         L = batch["label"][t].reshape(B, S)
         want_rows, want_lab = [], []
         for n in range(B):
             for p in range(S - 1):
-                if int(L[n, p + 1]) > 0:
+                if (int(L[n, p + 1]) >= 0) if t == "qav" else (int(L[n, p + 1]) > 0):
                     want_rows.append(n * S + p)
                     want_lab.append(int(L[n, p + 1]))
         m = batch[scored.COUNT][t]

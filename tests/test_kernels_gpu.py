@@ -994,22 +994,29 @@ def test_set_error_word_skips_the_optimizer_step_and_raises():
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gather_and_scatter_rows(dtype):
-    """fvqa_gather_rows / fvqa_scatter_rows (the scored-rows LM head's row movers): exact copies, zero rows where the index says so."""
+    """fvqa_gather_rows / fvqa_scatter_rows (the tail rows' row movers) over three streams: exact copies, zero rows where the map says so,
+    every dense row written."""
     torch.manual_seed(0)
-    R, D = 300, 4096
-    src = torch.randn(R, D, device="cuda").to(dtype)
-    idx = torch.tensor([5, 0, 299, 17, 17, 123, -1, 300], dtype=torch.int32, device="cuda")
-    dst = torch.full((idx.numel(), D), 7.0, device="cuda").to(dtype)
-    ops.gather_rows(src, idx, dst)
-    for j, r in enumerate(idx.tolist()):
-        want = src[r] if 0 <= r < R else torch.zeros(D, device="cuda", dtype=dtype)
-        assert torch.equal(dst[j], want), (j, r)
-    inv = torch.full((R,), -1, dtype=torch.int32, device="cuda")
-    inv[torch.tensor([3, 250, 299], device="cuda")] = torch.tensor([2, 0, 5], dtype=torch.int32, device="cuda")
-    out = torch.full((R, D), 3.0, device="cuda").to(dtype)
-    ops.scatter_rows(dst, inv, out)
+    SR, D = 100, 4096                                             # 3 streams of 100 dense rows
+    src = torch.randn(3 * SR, D, device="cuda").to(dtype)
+    idx = [torch.tensor(v, dtype=torch.int32, device="cuda") for v in ([5, 0, 99, 17], [17, 3], [42, -1, 100, 7, 7])]
+    offs = [0, 4, 6, 11]
+    dst = torch.full((11, D), 7.0, device="cuda").to(dtype)
+    ops.gather_rows(src, dst, ops.row_segs(idx, offs, SR))
+    j = 0
+    for k, v in enumerate(idx):
+        for r in v.tolist():
+            want = src[k * SR + r] if 0 <= r < SR else torch.zeros(D, device="cuda", dtype=dtype)
+            assert torch.equal(dst[j], want), (k, r)
+            j += 1
+    inv = [torch.full((SR,), -1, dtype=torch.int32, device="cuda") for _ in range(3)]
+    inv[0][3], inv[0][50] = 2, 0
+    inv[1][99] = 1
+    inv[2][0], inv[2][1] = 4, 9                                      # 9: outside the 5-row segment -> zero row
+    out = torch.full((3 * SR, D), 3.0, device="cuda").to(dtype)
+    ops.scatter_rows(dst, out, ops.row_segs(inv, offs, SR))
     ref = torch.zeros_like(out)
-    ref[3], ref[250], ref[299] = dst[2], dst[0], dst[5]
+    ref[3], ref[50], ref[SR + 99], ref[2 * SR + 0] = dst[2], dst[0], dst[4 + 1], dst[6 + 4]
     assert torch.equal(out, ref)
 
 

@@ -147,7 +147,7 @@ def test_scored_rows_head_against_reference_golden(case, dtype):
     losses, grads, logits, layer_out = run_step(model, batch, loss_weights=(w, w, w), lm_head="scored")
     grads = {n: g / w for n, g in grads.items()}
     sc = model._engine.last_scored
-    assert sc is not None and sc.M < batch["video"].shape[0] * cfg.max_seq_len      # the compact head ran, on fewer rows
+    assert sc is not None and sc.M < batch["video"].shape[0] * cfg.max_seq_len      # the compact tail ran, on fewer rows
     for t, lg in logits.items():                                                      # exactly the scored rows exist
         have = ~torch.isnan(lg[:, :, 0])
         lab = batch["label"][t].reshape(have.shape)
@@ -163,13 +163,15 @@ def test_scored_rows_head_against_reference_golden(case, dtype):
 
 
 @pytest.mark.parametrize("pname,over,dtype", [("tiny", dict(vaq=True, qav=True), torch.float32),
+                                              ("tiny", dict(vaq=True, qav=True, n_layers=1, adapter_layer=1), torch.float32),   # last == first layer
+                                              ("tiny", dict(qav=True), torch.bfloat16),                                        # vqa + qav, no vaq
                                               ("small", dict(vaq=True, qav=True), torch.float32),
                                               ("7b_l2", dict(batch_size=8, vaq=True, qav=True), torch.bfloat16),
                                               ("7b_l2", dict(batch_size=8), torch.bfloat16)])
 def test_scored_rows_head_equals_dense_head(pname, over, dtype):
-    """Same model, same batch, the head at every position against the head on the scored rows: the logits of the scored rows are
-    the same numbers (same kernel family, same K order), the losses agree to fp32 summation order, the gradients to the rounding
-    of the head's dX (its split along K differs with the row count)."""
+    """Same model, same batch, the dense form against the tail-rows form (last layer's post-attention half, heads and their backward
+    on the rows a head reads): layers before the last are bit-equal, the last layer's rows, the logits and the losses agree to the
+    rounding of projections whose kernels differ with the row count, and so do the gradients."""
     cfg = synth.preset(pname, **over)
     model, _ = build_model(cfg, dtype)
     batch = synth.make_batch(cfg, seed=3)
@@ -179,12 +181,18 @@ def test_scored_rows_head_equals_dense_head(pname, over, dtype):
         have = ~torch.isnan(lg_s[t][:, :, 0])
         assert have.any()
         a, b = lg_s[t][have], lg_d[t][have]
-        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), t
+        assert float((a - b).abs().max()) <= (2e-5 if dtype == torch.float32 else 2e-2) * float(b.abs().max()), t
     for t in l_d:
-        assert abs(l_d[t] - l_s[t]) <= 2e-6 * max(1.0, abs(l_d[t])), (t, l_d[t], l_s[t])
-    for a, b in zip(lo_d, lo_s):
-        assert torch.equal(a, b)
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
+        assert abs(l_d[t] - l_s[t]) <= (2e-6 if dtype == torch.float32 else 5e-3) * max(1.0, abs(l_d[t])), (t, l_d[t], l_s[t])
+    n_str = len(lo_d) // model._engine.L
+    for j, (a, b) in enumerate(zip(lo_d, lo_s)):
+        if j < len(lo_d) - n_str:
+            assert torch.equal(a, b)                                   # every layer but the last: the same kernels on the same rows
+        else:                                                          # the last layer: the rows a head reads, other kernel shapes
+            have = ~torch.isnan(b[:, :, 0])
+            assert have.any() and not have.all()
+            assert float((a[have] - b[have]).abs().max()) <= (1e-5 if dtype == torch.float32 else 3e-2) * float(a[have].abs().max())
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
     for n in g_d:
         den = float(g_d[n].abs().max())
         if den > 0:
@@ -202,7 +210,7 @@ def test_scored_rows_of_a_resident_batch():
     l_host, g_host, _, _ = run_step(model, host, lm_head="scored")
     assert scored.COUNT not in host                            # the caller's dict is left alone
     staged = fstep.stage_batch(host, "cuda")
-    assert staged["label"]["vqa"].is_cuda and staged["scored_idx"]["vaq"].is_cuda and set(staged[scored.COUNT]) == {"vqa", "vaq"}
+    assert staged["label"]["vqa"].is_cuda and staged["scored_idx"]["qav"].is_cuda and set(staged[scored.COUNT]) == {"vqa", "vaq", "qav"}
     l_st, g_st, _, _ = run_step(model, staged, lm_head="scored")
     assert model._engine.last_scored is not None
     assert l_host == l_st
@@ -345,19 +353,24 @@ def test_autograd_grad_mode_equals_flat_mode():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_native_schedule_equals_python_schedule(dtype, monkeypatch):
+@pytest.mark.parametrize("lm_head", ["all", "scored"])
+def test_native_schedule_equals_python_schedule(dtype, lm_head, monkeypatch):
     """csrc/schedule.hip (two calls per step) and the per-kernel Python schedule launch the same
-    kernels in the same order: bitwise-equal losses, logits and gradients."""
+    kernels in the same order: bitwise-equal losses, logits, layer outputs and gradients — in the dense form and with the last
+    layer's post-attention half on the tail rows."""
     cfg = synth.preset("small", vaq=True, qav=True)
     model, _ = build_model(cfg, dtype)
     batch = synth.make_batch(cfg, seed=6)
     monkeypatch.delenv("FVQA_PY_SCHEDULE", raising=False)
-    l_nat, g_nat, lg_nat, _ = run_step(model, batch)
+    l_nat, g_nat, lg_nat, lo_nat = run_step(model, batch, lm_head=lm_head)
     monkeypatch.setenv("FVQA_PY_SCHEDULE", "1")
-    l_py, g_py, lg_py, _ = run_step(model, batch)
+    l_py, g_py, lg_py, lo_py = run_step(model, batch, lm_head=lm_head)
     assert l_nat == l_py
+    nn = lambda x: torch.nan_to_num(x, nan=-7.0)              # noqa: E731
     for t in lg_nat:
-        assert torch.equal(lg_nat[t], lg_py[t]), t
+        assert torch.equal(nn(lg_nat[t]), nn(lg_py[t])), t
+    for a, b in zip(lo_nat, lo_py):
+        assert torch.equal(nn(a), nn(b))
     for n in g_nat:
         assert torch.equal(g_nat[n], g_py[n]), n
 

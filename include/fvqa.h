@@ -73,7 +73,8 @@ const char* fvqa_arch(void); /* "gfx950"                                     */
  * tail[(m - m_split)*N + n] (ACCUMULATED, +=) instead of C (adapter-query gradient rows).
  * Needs K % 64 == 0 (bf16) / K % 32 == 0 (fp32), 16-byte aligned rows.
  * variant 0 picks the kernel: the persistent 256x256-tile LDS-DMA ring kernel (M >= 192, N >= 256, N % 8 == 0, no
- * tail rows, workspace given; also 16 < M < 192 against >= 16 M weights: the projections of the tail rows, see fvqa_row_segs), the weight-streaming kernel of the generation path for bf16 M <= 16, K % 256 == 0 (one
+ * tail rows, workspace given; also 16 < M < 192 against >= 16 M weights: the projections of the tail rows, see
+ * fvqa_row_segs), the weight-streaming kernel of the generation path for bf16 M <= 16, K % 256 == 0 (one
  * new token per sequence, llama/model.py:439-447 run row-wise; with C == NULL, m_split == 0 it accumulates every row
  * into `tail`: the adapter-query gradient rows), else the 128x128-tile kernel. Other variant codes force a kernel
  * (1 / 2 = 128x128 register- / DMA-staged, 12 = weight-streaming, 13 = persistent; tests, tuning). */

@@ -555,7 +555,8 @@ def main():
 
         def name_of(kind):
             return ("f32" if kind & 64 else "bf16") + "_" + ("f32" if kind & 32 else "bf16") + "_" + \
-                epi_name.get(kind & 15, str(kind & 15)) + ("_splitk" if kind & 16 else "") + ("_4w" if kind & 128 else "")
+                epi_name.get(kind & 15, str(kind & 15)) + ("_splitk" if kind & 16 else "") + ("_4w" if kind & 128 else "") + \
+                ("_fewrows" if kind & 256 else "")
 
         R_ = a.batch_size * a.seq_len * (1 + int(a.vaq) + int(a.qav))
         Hf_ = model.layers[0].feed_forward.w1.weight.shape[0]

@@ -742,6 +742,10 @@ int fvqa_gemm4w_impl(int nbt, const void* A, const void* B, void* C, const void*
 // bytes whose first 4096 were zeroed once by the caller after allocation (epoch flags; never reset afterwards).
 // rider (may be NULL): see SkRider; *rode <- 1 when it was put on this launch's idle CUs (>= 16 of them, bf16), else 0
 // and the caller launches it on its own.
+int fvqa_fewrows_takes(int M, int N, int K, int dtype, int out_dtype, int epilogue, size_t scratch_bytes);
+int fvqa_fewrows_impl(const void* A, const void* B, void* C, const void* R, void* C2, float* scratch, int M, int N, int K, int lda,
+                      int ldb, int ldc, int out_dtype, int epilogue, hipStream_t st);
+
 int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void* ws, size_t ws_bytes, int M, int N,
                       int K, int lda, int ldb, int ldc, int dtype, int out_dtype, int epilogue, hipStream_t st,
                       const fvqa_sk_rider* rider, int* rode, void* C2, const fvqa_sk_rope* rope) {
@@ -756,6 +760,11 @@ int fvqa_gemm_sk_impl(const void* A, const void* B, void* C, const void* R, void
     // partners' flags would already match and partial tiles would race — refuse instead of corrupting silently
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return FVQA_EINVAL;
+  }
+  // 17..64 rows against a 7B-class weight matrix (the tail rows' projections): a weight stream, its own kernels (gemm_fewrows.hip)
+  if (!rider && !rope && fvqa_fewrows_takes(M, N, K, dtype, out_dtype, epilogue, ws_bytes - SYNC_BYTES)) {
+    if ((epilogue == FVQA_EPI_SWIGLU_FWD_ST) && (!C2 || ((uintptr_t)C2 & 15))) return FVQA_EINVAL;
+    return fvqa_fewrows_impl(A, B, C, R, C2, (float*)((char*)ws + SYNC_BYTES), M, N, K, lda, ldb, ldc, out_dtype, epilogue, st);
   }
   const int n_cu = cu_count();
   SkArgs a;

@@ -1053,3 +1053,51 @@ def test_library_bound_before_torch_is_imported_still_launches():
         "print('ok')\n") % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flipped-vqa_amd")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [17, 33, 48, 64])
+def test_few_rows_projections_every_epilogue(dtype, M):
+    """gemm_fewrows.hip — the tail rows' projections (17..64 rows against >= 16 M weights; fvqa_gemm_nt and the SwiGLU entries route
+    there): plain bf16 and fp32 outputs, + residual, the SwiGLU forward's (s, t, z) and the SwiGLU' pair, against fp64 at the tile
+    kernels' bounds; the same rows through the tile kernels (M = 192: the same values up to fp32 summation order); repeatable."""
+    D, Hf, V = 4096, 2048, 6144                              # N x K >= 2^24 for every shape below
+    x = rnd(M, D, dtype=dtype, seed=70 + M)
+    w = rnd(V, D, dtype=dtype, scale=1 / math.sqrt(D), seed=71)
+    ref = x.double() @ w.double().T
+    for out_dt in (dtype, torch.float32):
+        out = torch.full((M, V), 9.0, dtype=out_dt, device=DEV)
+        ops.gemm_nt(dev(x), dev(w), out)
+        assert rel(out, ref) < (1e-2 if out_dt != torch.float32 else 5e-6), out_dt
+        again = torch.empty_like(out)
+        ops.gemm_nt(dev(x), dev(w), again)
+        assert torch.equal(out, again)
+    big = torch.zeros(192, D, dtype=dtype)
+    big[:M] = x
+    out_big = torch.empty(192, V, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dev(big), dev(w), out_big)                   # tile kernels
+    assert float((out_big[:M].double().cpu() - out.double().cpu()).abs().max()) <= 2e-5 * float(ref.abs().max())
+    r = rnd(M, V, dtype=dtype, seed=72)
+    outr = torch.empty(M, V, dtype=dtype, device=DEV)
+    ops.gemm_nt(dev(x), dev(w), outr, residual=dev(r))
+    assert rel(outr, ref + r.double()) < 1e-2
+    # SwiGLU pair
+    w1, w3 = rnd(Hf, D, dtype=dtype, scale=2 / math.sqrt(D), seed=73), rnd(Hf, D, dtype=dtype, scale=2 / math.sqrt(D), seed=74)
+    w13 = ops.pack_ab16(w1.T.contiguous(), w3.T.contiguous()).T.contiguous()
+    st = torch.empty(M, 2 * Hf, dtype=dtype, device=DEV)
+    z = torch.empty(M, Hf, dtype=dtype, device=DEV)
+    ops.gemm_nt_swiglu_fwd(dev(x), dev(w13), st, z, st=True)
+    a, b = x.double() @ w1.double().T, x.double() @ w3.double().T
+    sg = torch.sigmoid(a)
+    s_ref, t_ref = a * sg, b * sg * (1 + a * (1 - sg))
+    gs, gt = ops.unpack_ab16(st)
+    assert rel(gs, s_ref) < 1e-2 and rel(gt, t_ref) < 1e-2 and rel(z, s_ref * b) < 2e-2
+    g = rnd(M, D, dtype=dtype, seed=75)
+    w2t = rnd(2 * Hf * 2, D, dtype=dtype, scale=1 / math.sqrt(D), seed=76)      # hidden = 8192: N x K = 2^25
+    st2 = rnd(M, 4 * Hf * 2, dtype=dtype, seed=77)
+    dab = torch.empty(M, 4 * Hf * 2, dtype=dtype, device=DEV)
+    ops.gemm_nt_swiglu_bwd(dev(g), dev(w2t), dev(st2), dab, st=True)
+    dz = g.double() @ w2t.double().T
+    s2, t2 = ops.unpack_ab16(st2)
+    ga, gb = ops.unpack_ab16(dab)
+    assert rel(ga, dz * t2.double()) < 1.5e-2 and rel(gb, dz * s2.double()) < 1.5e-2

@@ -619,7 +619,8 @@ def main():
                 from fvqa import build as fbuild
                 if pm.get("source_hash") == fbuild.source_hash():
                     w_ = [(v["launches_sampled"], v["hbm_bytes_per_launch"]) for k, v in pm.get("kernels", {}).items()
-                          if (k.startswith("gemm_sk_256") or "gemm4w_k" in k or "gemm4w_sk_k" in k) and "hbm_bytes_per_launch" in v]
+                          if (k.startswith("gemm_sk_256") or "gemm4w_k" in k or "gemm4w_sk_k" in k or "fewrows_partial_k" in k)
+                          and "hbm_bytes_per_launch" in v]
                     if w_:
                         traffic = sum(c * b for c, b in w_) / sum(c for c, _ in w_)
                         tsrc = f"profiles/{os.path.basename(tj)} (kernel sources {pm['source_hash'][:12]}, same workload)"

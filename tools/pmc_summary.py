@@ -21,7 +21,8 @@ import os
 import re
 import sys
 
-KEEP = ("gemm_sk_256", "gemm4w_sk_k", "fvqa_g4::gemm4w_k", "attn_fwd_mfma_k", "attn_bwd_fused_k", "rmsnorm_fwd_k", "rmsnorm_bwd_k", "gemm_nt_skinny")
+KEEP = ("gemm_sk_256", "gemm4w_sk_k", "fvqa_g4::gemm4w_k", "fewrows_partial_k", "fewrows_finish_k", "attn_fwd_mfma_k", "attn_bwd_fused_k",
+        "rmsnorm_fwd_k", "rmsnorm_bwd_k", "gemm_nt_skinny")
 N_CU = 256
 
 

@@ -51,7 +51,14 @@ __global__ __launch_bounds__(256) void fewrows_partial_k(const bf16_t* __restric
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[b][s] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int k = k0; k < k1; k += 32 * FR_U) {
+  // Batches are walked from a start that differs from workgroup to workgroup (and wave to wave): with K = 4096 the weight rows are
+  // 8 KiB apart, so waves that all sit at the same k ask the same few memory channels for everything (measured: the K = 4096 shapes
+  // streamed 3.4 TB/s, the K = 11008 / 22016 / 32000 ones 4.5). The sum of a column is still taken in one fixed order per launch.
+  const int nb = k1 > k0 ? (k1 - k0 + 32 * FR_U - 1) / (32 * FR_U) : 0;
+  const int rot = nb > 0 ? (int)((blockIdx.x * 5u + blockIdx.y * 3u + (unsigned)w) % (unsigned)nb) : 0;
+  for (int j = 0; j < nb; ++j) {
+    const int bi = j + rot < nb ? j + rot : j + rot - nb;
+    const int k = k0 + bi * 32 * FR_U;
     uint4 bf[FR_U][4], af[RB][FR_U];
 #pragma unroll
     for (int u = 0; u < FR_U; ++u) {

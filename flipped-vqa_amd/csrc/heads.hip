@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void visual_proj_fwd_k(const float* __restrict
 // dW[d,k] += sum_r (d_tok[r,d] + d_qav[r,d]) * video[r,k]   (the weight gradient of llama/model.py:322).
 // One wave owns DB output features and the whole K row of each in registers (DB x K/64 accumulators), so a frame row of
 // `video` fetched from L2 feeds DB features (DB x fewer bytes through L2 than one feature per wave), four rows per trip.
-template <int KMAX, int DB>
+template <int KMAX, int DB, int RT>   // RT frame rows per trip
 __global__ __launch_bounds__(256) void visual_proj_bwd_k(const float* __restrict__ d_tok,
                                                          const float* __restrict__ d_qav,
                                                          const float* __restrict__ video, float* __restrict__ dW,
@@ -58,11 +58,12 @@ __global__ __launch_bounds__(256) void visual_proj_bwd_k(const float* __restrict
   for (int j = 0; j < DB; ++j)
 #pragma unroll
     for (int t = 0; t < KMAX; ++t) acc[j][t] = 0.f;
-  for (int r0 = 0; r0 < R; r0 += 4) {                      // 4 frame rows per trip: their loads are all in flight together
-    float g[4][DB];
-    float v[4][KMAX];
+  for (int r0 = 0; r0 < R; r0 += RT) {                     // RT frame rows per trip: their loads are all in flight together (round 5: 8, was 4 —
+                                                           // the kernel is a chain of R / RT load latencies: 40.6 us at 20 trips)
+    float g[RT][DB];
+    float v[RT][KMAX];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < RT; ++rr) {
       const int r = r0 + rr < R ? r0 + rr : R - 1;
       const float live = r0 + rr < R ? 1.f : 0.f;
 #pragma unroll
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void visual_proj_bwd_k(const float* __restrict
       }
     }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)                         // rows in order: the same fma chain as a row-by-row loop
+    for (int rr = 0; rr < RT; ++rr)                        // rows in order: the same fma chain as a row-by-row loop
 #pragma unroll
       for (int j = 0; j < DB; ++j)
 #pragma unroll
@@ -124,17 +125,37 @@ __global__ __launch_bounds__(256) void visual_proj_fwd_mfma_k(const float* __res
   f32x4 acc[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < kw; k0 += 16) {
-    const float4 bf = *reinterpret_cast<const float4*>(bp + k0);
+  // four k-steps of 16 per trip, every load of the trip in flight before its first MFMA (round 5: one step per trip was a chain of
+  // twelve dependent load latencies, 28.9 us in the step); the accumulation order per output is unchanged (k ascending)
+  constexpr int VU = 4;
+  const float* ap[8];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      if (b >= nrb) break;
-      int ar = b * 16 + li; ar = ar < R ? ar : R - 1;
-      const float4 af = *reinterpret_cast<const float4*>(video + (size_t)ar * K + (size_t)w * kw + k0 + 4 * g);
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc[b], 0, 0, 0);     // D[row 4g+e][feature li]
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc[b], 0, 0, 0);
+  for (int b = 0; b < 8; ++b) {
+    int ar = b * 16 + li; ar = ar < R ? ar : R - 1;
+    ap[b] = video + (size_t)ar * K + (size_t)w * kw + 4 * g;
+  }
+  for (int k0 = 0; k0 < kw; k0 += 16 * VU) {
+    float4 bf[VU], af[VU][8];
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      const int k = k0 + 16 * u;
+      const bool in = k < kw;
+      bf[u] = in ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        af[u][b] = (in && b < nrb) ? *reinterpret_cast<const float4*>(ap[b] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+      if (k0 + 16 * u >= kw) break;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        if (b >= nrb) break;
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][b].x, bf[u].x, acc[b], 0, 0, 0);     // D[row 4g+e][feature li]
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][b].y, bf[u].y, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][b].z, bf[u].z, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][b].w, bf[u].w, acc[b], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -164,10 +185,35 @@ __global__ __launch_bounds__(256) void temporal_bwd_k(const float* __restrict__ 
 
 // ---- LM-head cross entropy (reference llama/model.py:349-350) --------------------------------
 // one workgroup per (n, s) row with s < S-1 and a non-ignored label; other rows exit at once
-__global__ __launch_bounds__(256) void ce_fwd_k(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                float* __restrict__ lse, float* __restrict__ rowloss, int S, int V,
-                                                int64_t ignore) {
-  __shared__ float red[4];
+// block-wide max / sum for blockDim.x == 1024 (16 waves); `red` is 16 floats of LDS
+__device__ __forceinline__ float block_max_1024(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float m = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+  return m;
+}
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) s += red[i];               // fixed order
+  return s;
+}
+
+// 1024 threads per row; a row of up to 32768 logits is read ONCE, all of its loads in flight together (round 5: the scored rows are
+// a few dozen workgroups, so a row's latency chain — two dependent passes of 31 loads per thread at 256 threads — was the kernel:
+// 16.7 us); longer rows take the two-pass loop.
+__global__ __launch_bounds__(1024) void ce_fwd_k(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 float* __restrict__ lse, float* __restrict__ rowloss, int S, int V,
+                                                 int64_t ignore) {
+  __shared__ float red[16];
   const int row = blockIdx.x;
   const int s = row % S;
   int64_t lab = ignore;
@@ -177,20 +223,35 @@ __global__ __launch_bounds__(256) void ce_fwd_k(const float* __restrict__ logits
     return;
   }
   const float* z = logits + (size_t)row * V;
-  float m = -INFINITY;
-  for (int c = threadIdx.x * 4; c < V; c += 1024) {
-    float v[4];
-    Vec4<float>::load(z + c, v);
-    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  constexpr int MAXC = 8;
+  float m = -INFINITY, sum = 0.f;
+  if (V <= 1024 * 4 * MAXC) {
+    float v[MAXC][4];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = (threadIdx.x + 1024 * i) * 4;
+      if (c < V) Vec4<float>::load(z + c, v[i]);
+      else v[i][0] = v[i][1] = v[i][2] = v[i][3] = -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) m = fmaxf(fmaxf(m, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+    m = block_max_1024(m, red);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) sum += __expf(v[i][0] - m) + __expf(v[i][1] - m) + __expf(v[i][2] - m) + __expf(v[i][3] - m);
+  } else {
+    for (int c = threadIdx.x * 4; c < V; c += 4096) {
+      float v[4];
+      Vec4<float>::load(z + c, v);
+      m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+    }
+    m = block_max_1024(m, red);
+    for (int c = threadIdx.x * 4; c < V; c += 4096) {
+      float v[4];
+      Vec4<float>::load(z + c, v);
+      sum += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
+    }
   }
-  m = block_max_256(m, red);
-  float sum = 0.f;
-  for (int c = threadIdx.x * 4; c < V; c += 1024) {
-    float v[4];
-    Vec4<float>::load(z + c, v);
-    sum += __expf(v[0] - m) + __expf(v[1] - m) + __expf(v[2] - m) + __expf(v[3] - m);
-  }
-  sum = block_sum_256(sum, red);
+  sum = block_sum_1024(sum, red);
   if (threadIdx.x == 0) {
     const float l = m + logf(sum);
     lse[row] = l;
@@ -217,7 +278,7 @@ __global__ __launch_bounds__(256) void loss_reduce_k(const float* __restrict__ r
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void ce_bwd_k(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+__global__ __launch_bounds__(1024) void ce_bwd_k(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                 const float* __restrict__ lse, const float* __restrict__ loss_sum,
                                                 const float* __restrict__ gscale, T* __restrict__ dlogits, int S,
                                                 int V, int64_t ignore) {
@@ -228,13 +289,13 @@ __global__ __launch_bounds__(256) void ce_bwd_k(const float* __restrict__ logits
   T* dz = dlogits + (size_t)row * V;
   if (lab == ignore || lab < 0 || lab >= V) {
     const float zero[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = threadIdx.x * 4; c < V; c += 1024) Vec4<T>::store(dz + c, zero);
+    for (int c = threadIdx.x * 4; c < V; c += 4096) Vec4<T>::store(dz + c, zero);
     return;
   }
   const float* z = logits + (size_t)row * V;
   const float l = lse[row];
   const float k = gscale[0] / loss_sum[1];
-  for (int c = threadIdx.x * 4; c < V; c += 1024) {
+  for (int c = threadIdx.x * 4; c < V; c += 4096) {
     float v[4], o[4];
     Vec4<float>::load(z + c, v);
 #pragma unroll
@@ -406,10 +467,10 @@ extern "C" int fvqa_visual_proj_bwd(const float* d_tok, const float* d_qav, cons
     return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
   if (in_dim <= 1024)        // 4 features per wave (4 x 16 accumulators), 4 waves per CU at D = 4096
-    hipLaunchKernelGGL((visual_proj_bwd_k<16, 4>), dim3((dim + 15) / 16), dim3(256), 0, st, d_tok, d_qav, video, dW,
+    hipLaunchKernelGGL((visual_proj_bwd_k<16, 4, 8>), dim3((dim + 15) / 16), dim3(256), 0, st, d_tok, d_qav, video, dW,
                        n_frames_total, in_dim, dim);
   else
-    hipLaunchKernelGGL((visual_proj_bwd_k<32, 2>), dim3((dim + 7) / 8), dim3(256), 0, st, d_tok, d_qav, video, dW,
+    hipLaunchKernelGGL((visual_proj_bwd_k<32, 2, 4>), dim3((dim + 7) / 8), dim3(256), 0, st, d_tok, d_qav, video, dW,
                        n_frames_total, in_dim, dim);
   hipLaunchKernelGGL(temporal_bwd_k, dim3((max_feats * dim + 255) / 256), dim3(256), 0, st, d_tok, dtemporal,
                      n_frames_total / max_feats, max_feats, dim);
@@ -423,7 +484,7 @@ extern "C" int fvqa_ce_fwd(const float* logits, const int64_t* labels, float* ls
   if (n_seq <= 0 || seq_len < 2 || vocab <= 0 || vocab % 4) return FVQA_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
   const int rows = n_seq * seq_len;
-  hipLaunchKernelGGL(ce_fwd_k, dim3(rows), dim3(256), 0, st, logits, labels, lse, rowloss, seq_len, vocab,
+  hipLaunchKernelGGL(ce_fwd_k, dim3(rows), dim3(1024), 0, st, logits, labels, lse, rowloss, seq_len, vocab,
                      ignore_index);
   hipLaunchKernelGGL(loss_reduce_k, dim3(1), dim3(256), 0, st, rowloss, labels, loss_sum, rows, seq_len,
                      ignore_index, (int64_t)vocab);
@@ -440,10 +501,10 @@ extern "C" int fvqa_ce_bwd(const float* logits, const int64_t* labels, const flo
   hipStream_t st = (hipStream_t)stream;
   const int rows = n_seq * seq_len;
   if (dtype == FVQA_H16)
-    hipLaunchKernelGGL(ce_bwd_k<bf16_t>, dim3(rows), dim3(256), 0, st, logits, labels, lse, loss_sum, gscale,
+    hipLaunchKernelGGL(ce_bwd_k<bf16_t>, dim3(rows), dim3(1024), 0, st, logits, labels, lse, loss_sum, gscale,
                        (bf16_t*)dlogits, seq_len, vocab, ignore_index);
   else
-    hipLaunchKernelGGL(ce_bwd_k<float>, dim3(rows), dim3(256), 0, st, logits, labels, lse, loss_sum, gscale,
+    hipLaunchKernelGGL(ce_bwd_k<float>, dim3(rows), dim3(1024), 0, st, logits, labels, lse, loss_sum, gscale,
                        (float*)dlogits, seq_len, vocab, ignore_index);
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;

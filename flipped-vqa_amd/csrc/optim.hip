@@ -50,28 +50,39 @@ __global__ __launch_bounds__(256) void unscale_sq_k(float* __restrict__ grad, co
   }
 }
 
-// one thread per segment sums its NB partials in fixed order; thread 0 then forms the total norm
+// one wave per segment sums its NB partials in a fixed order; thread 0 then forms the total norm
 // gemm_err (may be NULL): the error word of the persistent GEMM's workspace (include/fvqa.h). Non-zero = a split-K
 // exchange of some launch of this step timed out and its outputs are garbage: the step is skipped exactly like an
 // overflow (found_inf = 2 tells the host which of the two it was) — no extra device->host read on the step's path.
-__global__ __launch_bounds__(256) void norm_finish_k(const float* __restrict__ part, int n_seg,
+__global__ __launch_bounds__(1024) void norm_finish_k(const float* __restrict__ part, int n_seg,
                                                      float* __restrict__ seg_sq, float* __restrict__ found_inf,
                                                      float* __restrict__ total_norm,
                                                      const unsigned long long* __restrict__ gemm_err,
                                                      const float* __restrict__ err_lane) {
-  __shared__ float red[4];
+  __shared__ float red[16], redb[16];
+  // sixteen waves, a wave per segment at a time: lane l takes partials l, l + 64, ... in order, then a fixed butterfly (round 5: one
+  // THREAD per segment walked its NB partials one dependent load after the other: 10.7 us for 67 segments)
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float tot = 0.f, bad = 0.f;
-  for (int s = threadIdx.x; s < n_seg; s += 256) {
-    float a = 0.f;
-    for (int b = 0; b < NB; ++b) {
+  for (int s = w; s < n_seg; s += 16) {
+    float a = 0.f, bd = 0.f;
+    for (int b = lane; b < NB; b += 64) {
       a += part[((size_t)s * NB + b) * 2];
-      bad += part[((size_t)s * NB + b) * 2 + 1];
+      bd += part[((size_t)s * NB + b) * 2 + 1];
     }
-    seg_sq[s] = a;
-    tot += a;
+    a = wave_sum(a);
+    bd = wave_sum(bd);
+    if (lane == 0) {
+      seg_sq[s] = a;
+      tot += a;
+      bad += bd;
+    }
   }
-  tot = block_sum_256(tot, red);
-  bad = block_sum_256(bad, red);
+  if (lane == 0) { red[w] = tot; redb[w] = bad; }
+  __syncthreads();
+  tot = bad = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 16; ++i) { tot += red[i]; bad += redb[i]; }       // fixed order
   if (threadIdx.x == 0) {
     total_norm[0] = sqrtf(tot);
     float f = (bad > 0.f || !isfinite(tot)) ? 1.f : 0.f;
@@ -133,7 +144,7 @@ extern "C" int fvqa_grad_unscale_norm(float* grad, const int64_t* seg_off, int n
   if (workspace_bytes < fvqa_grad_norm_workspace(n_seg)) return FVQA_EALIGN;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(unscale_sq_k, dim3(NB, n_seg), dim3(256), 0, st, grad, seg_off, scale, grad_div, (float*)workspace);
-  hipLaunchKernelGGL(norm_finish_k, dim3(1), dim3(256), 0, st, (const float*)workspace, n_seg, seg_sq, found_inf,
+  hipLaunchKernelGGL(norm_finish_k, dim3(1), dim3(1024), 0, st, (const float*)workspace, n_seg, seg_sq, found_inf,
                      total_norm, (const unsigned long long*)gemm_err, err_lane);
   FVQA_CHECK_LAUNCH();
   return FVQA_OK;

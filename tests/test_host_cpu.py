@@ -448,3 +448,65 @@ def test_scored_rows_lists_match_the_cross_entropy_rule():
     # = NaN there, as torch's cross_entropy gives and engine.py:33-35 exits on)
     idx, inv, lab, m = scored.lists_of(torch.zeros(B, 1, S, dtype=torch.int64))
     assert m == 0 and scored.rows_of(0) == 2 and int(lab.abs().sum()) == 0 and int((inv >= 0).sum()) == 0
+
+
+def test_ctypes_mirrors_match_the_c_header(tmp_path):
+    """fvqa/_lib.py mirrors fvqa_layer_plan, fvqa_row_segs, fvqa_sk_rider and fvqa_sk_rope by hand: compile include/fvqa.h with gcc and
+    compare sizes and the offsets of the fields a mismatch would silently corrupt."""
+    import shutil
+    import subprocess
+    from fvqa import _lib
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "fvqa.h"\n'
+        'int main(void) {\n'
+        '  printf("%zu %zu %zu %zu\\n", sizeof(fvqa_layer_plan), sizeof(fvqa_row_segs), sizeof(fvqa_sk_rider), sizeof(fvqa_sk_rope));\n'
+        '  printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(fvqa_layer_plan, eps), offsetof(fvqa_layer_plan, wqkv), offsetof(fvqa_layer_plan, xs),\n'
+        '         offsetof(fvqa_layer_plan, gemm_ws_bytes), offsetof(fvqa_layer_plan, tail), offsetof(fvqa_row_segs, map));\n'
+        '  fvqa_layer_plan p; printf("%zu %zu %zu\\n", (size_t)((char*)&p.tail.gather - (char*)&p.tail), (size_t)((char*)&p.tail.og - (char*)&p.tail),\n'
+        '         (size_t)((char*)&p.tail.d_o - (char*)&p.tail));\n'
+        '  return 0;\n}\n')
+    exe = tmp_path / "sz"
+    subprocess.run([gcc, "-I", os.path.join(root, "include"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    got = [int(x) for x in out]
+    LP, RS, TR = _lib.LayerPlan, _lib.RowSegs, _lib.TailRows
+    want = [C.sizeof(LP), C.sizeof(RS), C.sizeof(_lib.SkRider), C.sizeof(_lib.SkRope),
+            LP.eps.offset, LP.wqkv.offset, LP.xs.offset, LP.gemm_ws_bytes.offset, LP.tail.offset, RS.map.offset,
+            TR.gather.offset, TR.og.offset, TR.d_o.offset]
+    assert got == want, (got, want)
+
+
+def test_bench_accounting_of_tail_rows():
+    """bench.py's two bookkeeping helpers for the tail rows: executed FLOPs (what the kernels multiplied) beside the contract's, and the
+    algorithmic bytes of a projection launch whose row count is its own."""
+    import importlib.util
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    D, Hf, V, B, S = 4096, 11008, 32000, 8, 128
+    fl = bench.step_flops(D, 32, 32, Hf, V, B, S, 10, 10, ["vqa"])
+    assert abs(fl - 27.366e12) < 0.01e12                                   # SURVEY 8d: 27.37 TF per C2 step
+    eng = types.SimpleNamespace(lm_head_rows="scored")
+    model = types.SimpleNamespace(ensure_engine=lambda: eng, params=types.SimpleNamespace(dim=D), vocab_size=V,
+                                  layers=[types.SimpleNamespace(feed_forward=types.SimpleNamespace(
+                                      w1=types.SimpleNamespace(weight=types.SimpleNamespace(shape=(Hf, D)))))])
+    batches = [{"scored_count": {"vqa": 32}} for _ in range(4)]
+    sr = bench.step_roofline_of(fl, 25.0, 2.5e15, model, batches, B, S, ["vqa"])
+    skipped = (1024 - 33) * (2.0 * D * V * 2 + 2.0 * (2.0 * D * D + 6.0 * D * Hf) * 2)
+    assert sr["lm_head_rows"] == "scored" and sr["tail_rows_per_step"] == 33 and sr["tail_rows_dense"] == 1024
+    assert abs(sr["executed_flops_per_step"] - (fl - skipped)) < 1e6 and sr["frac_executed"] < sr["frac"]
+    assert abs(sr["frac"] - fl / 25.0e-3 / 2.5e15) < 1e-12
+    eng.lm_head_rows = "all"
+    assert "frac_executed" not in bench.step_roofline_of(fl, 25.0, 2.5e15, model, batches, B, S, ["vqa"])
+    # a launch of 33 rows against W_out (fp32 logits) and against W1|W3^T: the row count comes from the launch's own FLOPs
+    b33 = bench.launch_alg_bytes(32, 2.0 * 33 * V * D, 1024, D, Hf, V)
+    assert b33 == 2.0 * 33 * D + 2.0 * V * D + 4.0 * 33 * V
+    b1024 = bench.launch_alg_bytes(32, 2.0 * 1024 * V * D, 1024, D, Hf, V)
+    assert b1024 == 2.0 * 1024 * D + 2.0 * V * D + 4.0 * 1024 * V
+    assert bench.launch_alg_bytes(0, 2.0 * 33 * D * 2 * Hf, 1024, D, Hf, V) == 2.0 * 33 * 2 * Hf + 2.0 * D * 2 * Hf + 2.0 * 33 * D

@@ -225,7 +225,8 @@ class StepEngine:
         self.saved = None
         self.last_scored = None
         self.keep_logits = False
-        # "scored": head, CE and head dX on the rows the CE scores (ScoredRows); "all": every position, as the reference
+        # "scored": the last layer's post-attention half, the heads and their backward on the rows a head reads (TailRows);
+        # "all": every position, as the reference
         self.lm_head_rows = "all" if os.environ.get("FVQA_LM_HEAD", "scored") == "all" else "scored"
 
     # ------------------------------------------------------------------ native layer schedule

@@ -43,9 +43,10 @@ def build_model(cfg, dtype=torch.float32, device="cuda"):
 def run_step(model, batch, loss_weights=(1.0, 1.0, 1.0), lm_head="all"):
     """forward + backward of w·losses; returns losses dict, grads dict (CPU fp32), logits dict, layer outs.
 
-    lm_head: "all" = the LM head at every position, as the reference evaluates it (the parity tests compare the logits of every
-    row); "scored" = the product default, head + CE + head dX on the scored rows only (fvqa/step.py ScoredRows) — the logits
-    dict then holds NaN rows wherever the cross-entropy ignores the row."""
+    lm_head: "all" = the reference's dense form — every projection of the last layer and the LM head at every position (the parity
+    tests compare the logits of every row); "scored" = the product default: the last layer's post-attention half, the heads and their
+    backward on the rows a head reads only (fvqa/step.py TailRows) — the logits and the last layer's output then hold NaN rows
+    everywhere else."""
     model.ensure_engine().lm_head_rows = lm_head
     flat = model.flat_params()
     flat.zero_grad()

@@ -134,11 +134,11 @@ SCORED_CASES = [("tiny_all", torch.float32), ("tiny_vqa", torch.float32), ("smal
 
 @pytest.mark.parametrize("case,dtype", SCORED_CASES)
 def test_scored_rows_head_against_reference_golden(case, dtype):
-    """The product default — LM head, cross-entropy and the head's dX on the rows the cross-entropy scores, nothing for the rows it
-    ignores (fvqa/step.py ScoredRows; the reference evaluates the head at every position, llama/model.py:348-350) — against the
-    reference's goldens at the same bounds as the dense form: the three losses, every trainable's gradient, every layer output,
-    and the logits (sampled values, token argmax) of the scored rows. C2's, C3's, C4's and C5's shapes and the benchmarked
-    workload at full depth."""
+    """The product default — the last layer's post-attention half, the heads and all of their backward on the rows a head reads,
+    nothing for the rows no head reads (fvqa/step.py TailRows; the reference runs every row through everything,
+    llama/model.py:184-187, 346-350) — against the reference's goldens at the same bounds as the dense form: the three losses, every
+    trainable's gradient, every layer output (the last layer's on the rows that exist), and the logits (sampled values, token argmax)
+    of the scored rows. C2's, C3's, C4's and C5's shapes and the benchmarked workload at full depth."""
     pname, over = CASES[case]
     cfg = synth.preset(pname, **over)
     model, _ = build_model(cfg, dtype)
